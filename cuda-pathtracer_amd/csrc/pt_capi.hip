@@ -1,0 +1,650 @@
+// C-ABI of the render path (include/pt_capi.h): context, uploads, BVH flattening, launches.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include <new>
+#include "../../include/pt_capi.h"
+#include "../../include/pt_detmath.h"
+#include "pt_internal.h"
+#include "pt_layout.h"
+#include "pt_launch.h"
+
+namespace ptamd { const char* last_error(); }
+using namespace ptamd;
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t e__ = (expr);                                                              \
+        if (e__ != hipSuccess) {                                                              \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return PT_ERR_HIP;                                                                \
+        }                                                                                     \
+    } while (0)
+
+struct pt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int W = 0, H = 0;
+    float* accum = nullptr;         // 3*W*H
+    uint8_t* display = nullptr;     // 4*W*H
+    // scene, host copies
+    std::vector<pt_triangle> tris;
+    std::vector<int> tri_idx;
+    // scene, device
+    pt_triangle* d_tri_ref = nullptr;
+    DTri* d_tris = nullptr;
+    DNode* d_nodes = nullptr;
+    DMat* d_mats = nullptr;
+    DTex* d_tex = nullptr;
+    std::vector<DTex> tex_table;
+    std::vector<float*> tex_data;
+    float* d_env = nullptr;
+    float* d_cdf = nullptr;
+    DScene scene{};
+    bool have_tris = false, have_bvh = false, have_mats = false, have_env = false;
+    int max_bounces = 512;
+    bool counting = false;
+    DCounters* d_ctr = nullptr;
+    pt_counters totals{};
+    size_t n_nodes = 0;
+};
+
+extern "C" {
+
+const char* pt_last_error(void) { return ptamd::last_error(); }
+
+int pt_create(pt_ctx** out, int device_id)
+{
+    if (!out) { set_error("pt_create: null output"); return PT_ERR_ARG; }
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        set_error("pt_create: no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+        return PT_ERR_HIP;
+    }
+    if (device_id < 0 || device_id >= count) { set_error("pt_create: device %d out of range (%d devices)", device_id, count); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(device_id));
+    pt_ctx* c = new (std::nothrow) pt_ctx();
+    if (!c) { set_error("out of memory"); return PT_ERR_NOMEM; }
+    c->device = device_id;
+    HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
+    c->stream = c->own_stream;
+    HIP_TRY(hipEventCreate(&c->ev0));
+    HIP_TRY(hipEventCreate(&c->ev1));
+    HIP_TRY(hipMalloc((void**)&c->d_ctr, sizeof(DCounters)));
+    HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(DCounters)));
+    c->scene.sky_mode = PT_SKY_ENVMAP;
+    c->scene.sun[0] = 0.f; c->scene.sun[1] = 1.f; c->scene.sun[2] = 0.f;
+    *out = c;
+    return PT_OK;
+}
+
+static void free_scene_geometry(pt_ctx* c)
+{
+    if (c->d_tris) { (void)hipFree(c->d_tris); c->d_tris = nullptr; }
+    if (c->d_nodes) { (void)hipFree(c->d_nodes); c->d_nodes = nullptr; }
+    c->have_bvh = false;
+}
+
+void pt_destroy(pt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    free_scene_geometry(c);
+    if (c->d_tri_ref) (void)hipFree(c->d_tri_ref);
+    if (c->d_mats) (void)hipFree(c->d_mats);
+    if (c->d_tex) (void)hipFree(c->d_tex);
+    for (float* p : c->tex_data) (void)hipFree(p);
+    if (c->d_env) (void)hipFree(c->d_env);
+    if (c->d_cdf) (void)hipFree(c->d_cdf);
+    if (c->accum) (void)hipFree(c->accum);
+    if (c->display) (void)hipFree(c->display);
+    if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+int pt_set_stream(pt_ctx* c, void* s)
+{
+    if (!c) { set_error("null context"); return PT_ERR_ARG; }
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return PT_OK;
+}
+
+int pt_init(pt_ctx* c, const pt_params* p)
+{
+    if (!c || !p) { set_error("pt_init: null argument"); return PT_ERR_ARG; }
+    int W = p->windowSize.x, H = p->windowSize.y;
+    if (W <= 0 || H <= 0 || (int64_t)W * H > (1 << 28)) { set_error("pt_init: bad window size %dx%d", W, H); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->accum) { (void)hipFree(c->accum); c->accum = nullptr; }
+    if (c->display) { (void)hipFree(c->display); c->display = nullptr; }
+    HIP_TRY(hipMalloc((void**)&c->accum, (size_t)W * H * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->display, (size_t)W * H * 4));
+    HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)W * H * 3 * sizeof(float), c->stream));
+    HIP_TRY(hipMemsetAsync(c->display, 0, (size_t)W * H * 4, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->W = W; c->H = H;
+    return PT_OK;
+}
+
+int pt_clear_accum(pt_ctx* c)
+{
+    if (!c || !c->accum) { set_error("pt_clear_accum: not initialised"); return PT_ERR_STATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)c->W * c->H * 3 * sizeof(float), c->stream));
+    return PT_OK;
+}
+
+int pt_upload_triangles(pt_ctx* c, const int* tri_idx, const pt_triangle* tris, int n)
+{
+    if (!c || !tris || n <= 0) { set_error("pt_upload_triangles: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    c->tris.assign(tris, tris + n);
+    c->tri_idx.resize(n);
+    for (int i = 0; i < n; i++) {
+        int v = tri_idx ? tri_idx[i] : i;
+        if (v < 0 || v >= n) { set_error("pt_upload_triangles: index %d out of range at %d", v, i); return PT_ERR_ARG; }
+        c->tri_idx[i] = v;
+    }
+    if (c->d_tri_ref) { (void)hipFree(c->d_tri_ref); c->d_tri_ref = nullptr; }
+    free_scene_geometry(c);
+    HIP_TRY(hipMalloc((void**)&c->d_tri_ref, (size_t)n * sizeof(pt_triangle)));
+    HIP_TRY(hipMemcpy(c->d_tri_ref, tris, (size_t)n * sizeof(pt_triangle), hipMemcpyHostToDevice));
+    c->scene.tri_ref = c->d_tri_ref;
+    c->scene.n_tris = n;
+    c->have_tris = true;
+    return PT_OK;
+}
+
+static int tex_slot(const pt_ctx* c, uint64_t handle, uint8_t flag, int comps, const char* what, int mat, int* out)
+{
+    *out = 0;
+    if (!flag || handle == 0) return PT_OK;
+    if (handle > c->tex_table.size()) { set_error("material %d: %s handle %llu is not an uploaded texture", mat, what, (unsigned long long)handle); return PT_ERR_ARG; }
+    if (c->tex_table[handle - 1].comps != comps) { set_error("material %d: %s needs a %d-component texture", mat, what, comps); return PT_ERR_ARG; }
+    *out = (int)handle;
+    return PT_OK;
+}
+
+int pt_upload_materials(pt_ctx* c, const pt_material* mats, int n)
+{
+    if (!c || !mats || n <= 0) { set_error("pt_upload_materials: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<DMat> dm(n);
+    for (int i = 0; i < n; i++) {
+        const pt_material& m = mats[i];
+        DMat& d = dm[i];
+        memset(&d, 0, sizeof(d));
+        d.base[0] = m.baseColor.x; d.base[1] = m.baseColor.y; d.base[2] = m.baseColor.z;
+        d.emis[0] = m.emissive.x; d.emis[1] = m.emissive.y; d.emis[2] = m.emissive.z;
+        d.rough = m.roughness; d.aniso = m.anisotropic; d.metal = m.metallic; d.subsurf = m.subsurface; d.sheen = m.sheen;
+        d.coat = m.clearcoat; d.coat_rough = m.clearcoatRoughness; d.strans = m.specTrans; d.alpha = m.alpha; d.ior = m.ior;
+        d.G = m.medium.G;
+        d.sigA[0] = m.medium.sigmaA.x; d.sigA[1] = m.medium.sigmaA.y; d.sigA[2] = m.medium.sigmaA.z;
+        d.sigS[0] = m.medium.sigmaS.x; d.sigS[1] = m.medium.sigmaS.y; d.sigS[2] = m.medium.sigmaS.z;
+        int rc;
+        if ((rc = tex_slot(c, m.diffuseTexture, m.useTexture, 4, "map_Kd", i, &d.tex_diffuse)) != PT_OK) return rc;
+        if ((rc = tex_slot(c, m.roughnessTexture, m.use_mapPr, 1, "map_Pr", i, &d.tex_rough)) != PT_OK) return rc;
+        if ((rc = tex_slot(c, m.metallicTexture, m.use_mapPm, 1, "map_Pm", i, &d.tex_metal)) != PT_OK) return rc;
+        if ((rc = tex_slot(c, m.emissiveTexture, m.use_mapKe, 1, "map_Ke", i, &d.tex_emis)) != PT_OK) return rc;
+        if ((rc = tex_slot(c, m.normalTexture, m.use_mapNor, 4, "map_Bump", i, &d.tex_normal)) != PT_OK) return rc;
+    }
+    if (c->have_tris) {
+        for (size_t i = 0; i < c->tris.size(); i++)
+            if (c->tris[i].matIndex < 0 || c->tris[i].matIndex >= n) { set_error("triangle %zu uses material %d of %d", i, c->tris[i].matIndex, n); return PT_ERR_ARG; }
+    }
+    if (c->d_mats) { (void)hipFree(c->d_mats); c->d_mats = nullptr; }
+    HIP_TRY(hipMalloc((void**)&c->d_mats, (size_t)n * sizeof(DMat)));
+    HIP_TRY(hipMemcpy(c->d_mats, dm.data(), (size_t)n * sizeof(DMat), hipMemcpyHostToDevice));
+    if (c->d_tex) { (void)hipFree(c->d_tex); c->d_tex = nullptr; }
+    if (!c->tex_table.empty()) {
+        HIP_TRY(hipMalloc((void**)&c->d_tex, c->tex_table.size() * sizeof(DTex)));
+        HIP_TRY(hipMemcpy(c->d_tex, c->tex_table.data(), c->tex_table.size() * sizeof(DTex), hipMemcpyHostToDevice));
+    }
+    c->scene.mats = c->d_mats;
+    c->scene.tex = c->d_tex;
+    c->have_mats = true;
+    return PT_OK;
+}
+
+// Re-flattens the reference's 32-byte nodes (structs.cuh:130-137) into 64-byte two-box nodes and
+// lays triangles out in leaf order. Interior nodes are numbered in depth-first order.
+int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_used, int n_tri)
+{
+    if (!c || !nodes || nodes_used <= 0) { set_error("pt_upload_bvh: bad argument"); return PT_ERR_ARG; }
+    if (!c->have_tris || n_tri != (int)c->tris.size()) { set_error("pt_upload_bvh: upload %d triangles first", n_tri); return PT_ERR_STATE; }
+    if (root_idx < 0 || root_idx >= nodes_used) { set_error("pt_upload_bvh: bad root"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    std::vector<DNode> dn;
+    std::vector<DTri> dt;
+    dn.reserve(nodes_used / 2 + 1);
+    dt.reserve(n_tri);
+    std::vector<char> seen(n_tri, 0);
+    auto emit_leaf = [&](const pt_bvh_node& nd, int* ref) -> int {
+        if (nd.triCount <= 0 || nd.leftFirst < 0 || (int64_t)nd.leftFirst + nd.triCount > n_tri) { set_error("pt_upload_bvh: leaf range [%d,+%d) out of bounds", nd.leftFirst, nd.triCount); return PT_ERR_ARG; }
+        int first = (int)dt.size();
+        for (int i = 0; i < nd.triCount; i++) {
+            int id = c->tri_idx[nd.leftFirst + i];
+            const pt_triangle& T = c->tris[id];
+            seen[id] = 1;
+            DTri r;
+            r.q0 = make_float4(T.a.x, T.a.y, T.a.z, __builtin_bit_cast(float, (uint32_t)id));
+            r.q1 = make_float4(T.b.x - T.a.x, T.b.y - T.a.y, T.b.z - T.a.z, __builtin_bit_cast(float, i == 0 ? nd.triCount : 0));
+            r.q2 = make_float4(T.c.x - T.a.x, T.c.y - T.a.y, T.c.z - T.a.z, 0.f);
+            dt.push_back(r);
+        }
+        *ref = ~first;
+        return PT_OK;
+    };
+    const pt_bvh_node& root = nodes[root_idx];
+    if (root.triCount > 0) {
+        int ref;
+        int rc = emit_leaf(root, &ref);
+        if (rc != PT_OK) return rc;
+        c->scene.root_ref = ref;
+        dn.push_back(DNode{});     // keep the node buffer non-empty
+    } else {
+        struct Item { int src; int dst; };
+        std::vector<Item> st;
+        dn.push_back(DNode{});
+        st.push_back(Item{root_idx, 0});
+        c->scene.root_ref = 0;
+        while (!st.empty()) {
+            Item it = st.back(); st.pop_back();
+            const pt_bvh_node& nd = nodes[it.src];
+            int l = nd.leftFirst, r = nd.leftFirst + 1;
+            if (l <= 0 || r >= nodes_used) { set_error("pt_upload_bvh: node %d has children out of range", it.src); return PT_ERR_ARG; }
+            const pt_bvh_node& L = nodes[l];
+            const pt_bvh_node& R = nodes[r];
+            DNode d{};
+            d.lmin[0] = L.aabbMin.x; d.lmin[1] = L.aabbMin.y; d.lmin[2] = L.aabbMin.z;
+            d.lmax[0] = L.aabbMax.x; d.lmax[1] = L.aabbMax.y; d.lmax[2] = L.aabbMax.z;
+            d.rmin[0] = R.aabbMin.x; d.rmin[1] = R.aabbMin.y; d.rmin[2] = R.aabbMin.z;
+            d.rmax[0] = R.aabbMax.x; d.rmax[1] = R.aabbMax.y; d.rmax[2] = R.aabbMax.z;
+            // left subtree first, so it is contiguous right after its parent
+            int rc;
+            if (L.triCount > 0) { if ((rc = emit_leaf(L, &d.left)) != PT_OK) return rc; }
+            else { d.left = (int)dn.size(); dn.push_back(DNode{}); }
+            if (R.triCount > 0) { if ((rc = emit_leaf(R, &d.right)) != PT_OK) return rc; }
+            else { d.right = (int)dn.size(); dn.push_back(DNode{}); }
+            if ((int)dn.size() > nodes_used) { set_error("pt_upload_bvh: cyclic node graph"); return PT_ERR_ARG; }
+            if (R.triCount <= 0) st.push_back(Item{r, d.right});
+            if (L.triCount <= 0) st.push_back(Item{l, d.left});
+            dn[it.dst] = d;
+        }
+    }
+    c->scene.root_min[0] = root.aabbMin.x; c->scene.root_min[1] = root.aabbMin.y; c->scene.root_min[2] = root.aabbMin.z;
+    c->scene.root_max[0] = root.aabbMax.x; c->scene.root_max[1] = root.aabbMax.y; c->scene.root_max[2] = root.aabbMax.z;
+    free_scene_geometry(c);
+    HIP_TRY(hipMalloc((void**)&c->d_nodes, dn.size() * sizeof(DNode)));
+    HIP_TRY(hipMemcpy(c->d_nodes, dn.data(), dn.size() * sizeof(DNode), hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void**)&c->d_tris, (dt.size() + 1) * sizeof(DTri)));
+    HIP_TRY(hipMemcpy(c->d_tris, dt.data(), dt.size() * sizeof(DTri), hipMemcpyHostToDevice));
+    c->scene.nodes = c->d_nodes;
+    c->scene.tris = c->d_tris;
+    c->n_nodes = dn.size();
+    c->have_bvh = true;
+    return PT_OK;
+}
+
+int pt_build_bvh(pt_ctx* c, int flavour)
+{
+    if (!c || !c->have_tris) { set_error("pt_build_bvh: upload triangles first"); return PT_ERR_STATE; }
+    if (flavour != PT_BVH_REFERENCE) { set_error("pt_build_bvh: unknown flavour %d", flavour); return PT_ERR_ARG; }
+    int n = (int)c->tris.size();
+    std::vector<pt_bvh_node> nodes((size_t)2 * n - 1 + 1);
+    for (int i = 0; i < n; i++) c->tri_idx[i] = i;
+    int used = 0;
+    int rc = build_bvh_reference(c->tris.data(), c->tri_idx.data(), n, nodes.data(), &used);
+    if (rc != PT_OK) return rc;
+    return pt_upload_bvh(c, nodes.data(), 0, used, n);
+}
+
+int pt_upload_texture(pt_ctx* c, const float* texels, int w, int h, int comps, uint64_t* handle_out)
+{
+    if (!c || !texels || !handle_out || w <= 0 || h <= 0 || (comps != 1 && comps != 4)) { set_error("pt_upload_texture: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    float* d = nullptr;
+    size_t bytes = (size_t)w * h * comps * sizeof(float);
+    HIP_TRY(hipMalloc((void**)&d, bytes));
+    HIP_TRY(hipMemcpy(d, texels, bytes, hipMemcpyHostToDevice));
+    c->tex_data.push_back(d);
+    DTex t; t.texels = d; t.w = w; t.h = h; t.comps = comps; t.pad = 0;
+    c->tex_table.push_back(t);
+    *handle_out = (uint64_t)c->tex_table.size();
+    return PT_OK;
+}
+
+int pt_upload_envmap(pt_ctx* c, const float* rgba, const float* cdf, int w, int h, float sum, pt_params* params_io)
+{
+    if (!c || !rgba || !cdf || w <= 0 || h <= 0) { set_error("pt_upload_envmap: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    if (c->d_env) { (void)hipFree(c->d_env); c->d_env = nullptr; }
+    if (c->d_cdf) { (void)hipFree(c->d_cdf); c->d_cdf = nullptr; }
+    HIP_TRY(hipMalloc((void**)&c->d_env, (size_t)w * h * 4 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->d_cdf, (size_t)w * h * sizeof(float)));
+    HIP_TRY(hipMemcpy(c->d_env, rgba, (size_t)w * h * 4 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->d_cdf, cdf, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice));
+    c->scene.env_rgba = c->d_env; c->scene.env_cdf = c->d_cdf;
+    c->scene.env_w = w; c->scene.env_h = h; c->scene.env_sum = sum;
+    c->have_env = true;
+    if (params_io) {
+        params_io->envMap_size.x = w; params_io->envMap_size.y = h; params_io->envmap_sum = sum;
+        params_io->cubeMap = 1; params_io->envMap_cdf = 1;
+    }
+    return PT_OK;
+}
+
+int pt_set_sky_mode(pt_ctx* c, int mode)
+{
+    if (!c || (mode != PT_SKY_ENVMAP && mode != PT_SKY_SUNSKY)) { set_error("pt_set_sky_mode: bad argument"); return PT_ERR_ARG; }
+    c->scene.sky_mode = mode;
+    return PT_OK;
+}
+
+int pt_set_max_bounces(pt_ctx* c, int n)
+{
+    if (!c || n < 0) { set_error("pt_set_max_bounces: bad argument"); return PT_ERR_ARG; }
+    c->max_bounces = n;
+    return PT_OK;
+}
+
+int pt_enable_counters(pt_ctx* c, int on)
+{
+    if (!c) { set_error("null context"); return PT_ERR_ARG; }
+    c->counting = on != 0;
+    return PT_OK;
+}
+
+int pt_camera_basis(const pt_params* P, pt_float3* ww, pt_float3* uu, pt_float3* vv)
+{
+    if (!P || !ww || !uu || !vv) { set_error("pt_camera_basis: null argument"); return PT_ERR_ARG; }
+    // pathtracer.cu:568-571 with the pinned sin/cos and rsqrtf = 1/sqrtf
+    auto unit = [](float x, float y, float z, pt_float3* o) { float s = 1.0f / __builtin_sqrtf(x * x + y * y + z * z); o->x = x * s; o->y = y * s; o->z = z * s; };
+    float ax = P->cameraAngle.x, ay = P->cameraAngle.y;
+    float ox = P->rayOrigin.x, oy = P->rayOrigin.y, oz = P->rayOrigin.z;
+    float tx = ox + pt_sinf(ax) * pt_cosf(ay), ty = oy + pt_sinf(ay), tz = oz + -pt_cosf(ax) * pt_cosf(ay);
+    unit(tx - ox, ty - oy, tz - oz, ww);
+    // cross(ww, (0,1,0)) and cross(uu, ww) component by component (float3_header.cuh:80-82)
+    float cx = ww->y * 0.f - 1.f * ww->z, cy = ww->z * 0.f - 0.f * ww->x, cz = ww->x * 1.f - 0.f * ww->y;
+    unit(cx, cy, cz, uu);
+    float dx = uu->y * ww->z - ww->y * uu->z, dy = uu->z * ww->x - ww->z * uu->x, dz = uu->x * ww->y - ww->x * uu->y;
+    unit(dx, dy, dz, vv);
+    return PT_OK;
+}
+
+static int make_camera(pt_ctx* c, const pt_params* P, DCamera* cam)
+{
+    if (P->windowSize.x != c->W || P->windowSize.y != c->H) { set_error("window size %dx%d differs from pt_init's %dx%d", P->windowSize.x, P->windowSize.y, c->W, c->H); return PT_ERR_ARG; }
+    pt_float3 ww, uu, vv;
+    pt_camera_basis(P, &ww, &uu, &vv);
+    cam->origin[0] = P->rayOrigin.x; cam->origin[1] = P->rayOrigin.y; cam->origin[2] = P->rayOrigin.z;
+    cam->ww[0] = ww.x; cam->ww[1] = ww.y; cam->ww[2] = ww.z;
+    cam->uu[0] = uu.x; cam->uu[1] = uu.y; cam->uu[2] = uu.z;
+    cam->vv[0] = vv.x; cam->vv[1] = vv.y; cam->vv[2] = vv.z;
+    cam->fov = P->fov; cam->focal = P->focalDistance; cam->dof = P->DOF_strenght;
+    cam->W = c->W; cam->H = c->H;
+    cam->is_rendering = P->isRendering ? 1 : 0;
+    cam->max_bounces = c->max_bounces;
+    c->scene.sun[0] = P->sunDirection.x; c->scene.sun[1] = P->sunDirection.y; c->scene.sun[2] = P->sunDirection.z;
+    return PT_OK;
+}
+
+static int check_ready(pt_ctx* c, bool need_image)
+{
+    if (!c) { set_error("null context"); return PT_ERR_ARG; }
+    if (!c->have_tris || !c->have_bvh) { set_error("scene not ready: upload triangles and a BVH first"); return PT_ERR_STATE; }
+    if (need_image) {
+        if (!c->accum) { set_error("pt_init has not been called"); return PT_ERR_STATE; }
+        if (!c->have_mats) { set_error("scene not ready: upload materials first"); return PT_ERR_STATE; }
+        if (c->scene.sky_mode == PT_SKY_ENVMAP && !c->have_env) { set_error("scene not ready: upload an environment map or select the sun/sky model"); return PT_ERR_STATE; }
+    }
+    return PT_OK;
+}
+
+static int fetch_counters(pt_ctx* c)
+{
+    DCounters h;
+    HIP_TRY(hipMemcpyAsync(&h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->totals.rays += h.rays; c->totals.samples += h.samples; c->totals.box_tests += h.box_tests; c->totals.tri_tests += h.tri_tests;
+    c->totals.shade_vertices += h.shade_vertices; c->totals.env_samples += h.env_samples; c->totals.tex_taps += h.tex_taps;
+    HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(DCounters), c->stream));
+    return PT_OK;
+}
+
+int pt_render_headless(pt_ctx* c, const pt_params* P, int frame_begin, int frame_end)
+{
+    int rc = check_ready(c, true);
+    if (rc != PT_OK) return rc;
+    if (!P || frame_begin < 0 || frame_end < frame_begin || frame_end > 524288) { set_error("pt_render_headless: bad frame range [%d,%d)", frame_begin, frame_end); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    DCamera cam;
+    if ((rc = make_camera(c, P, &cam)) != PT_OK) return rc;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    launch_render_samples(c->scene, cam, frame_begin, frame_end, c->accum, c->counting ? c->d_ctr : nullptr, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    if (c->counting) { if ((rc = fetch_counters(c)) != PT_OK) return rc; }
+    return PT_OK;
+}
+
+int pt_sync(pt_ctx* c)
+{
+    if (!c) { set_error("null context"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->totals.last_ms = ms;
+    return PT_OK;
+}
+
+int pt_render_frame(pt_ctx* c, pt_params* P)
+{
+    int rc = check_ready(c, true);
+    if (rc != PT_OK) return rc;
+    if (!P) { set_error("pt_render_frame: null params"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    // pathtracer.cu:583-586: the first frame of a render and every preview frame overwrite
+    if (P->frameIndex == 0 || !P->isRendering) { if ((rc = pt_clear_accum(c)) != PT_OK) return rc; }
+    if ((rc = pt_render_headless(c, P, P->frameIndex, P->frameIndex + 1)) != PT_OK) return rc;
+    launch_resolve_display(c->accum, c->W * c->H, P->isRendering ? P->frameIndex + 1 : 1, c->display, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (P->pixelBuffer) HIP_TRY(hipMemcpyAsync(P->pixelBuffer, c->display, (size_t)c->W * c->H * 4, hipMemcpyDeviceToHost, c->stream));
+    return pt_sync(c);
+}
+
+int pt_read_accum(pt_ctx* c, float* out)
+{
+    if (!c || !out || !c->accum) { set_error("pt_read_accum: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(out, c->accum, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    return pt_sync(c);
+}
+
+int pt_write_accum(pt_ctx* c, const float* in)
+{
+    if (!c || !in || !c->accum) { set_error("pt_write_accum: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipMemcpyAsync(c->accum, in, (size_t)c->W * c->H * 3 * sizeof(float), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_accum_device_ptr(pt_ctx* c, float** out)
+{
+    if (!c || !out || !c->accum) { set_error("pt_accum_device_ptr: bad argument"); return PT_ERR_ARG; }
+    *out = c->accum;
+    return PT_OK;
+}
+
+int pt_resolve_display(pt_ctx* c, int n_frames, uint8_t* rgba_out)
+{
+    if (!c || !c->accum || n_frames <= 0) { set_error("pt_resolve_display: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    launch_resolve_display(c->accum, c->W * c->H, n_frames, c->display, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, c->display, (size_t)c->W * c->H * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_save_png(const char* path, const uint8_t* rgba, int w, int h) { return save_png(path, rgba, w, h); }
+
+int pt_trace_closest_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* hits_dev)
+{
+    int rc = check_ready(c, false);
+    if (rc != PT_OK) return rc;
+    if (n < 0 || (n > 0 && (!rays_dev || !hits_dev))) { set_error("pt_trace_closest_dev: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    launch_trace_closest(c->scene, rays_dev, n, hits_dev, nullptr, nullptr, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    return PT_OK;
+}
+
+int pt_trace_closest_counted(pt_ctx* c, const pt_ray* rays, int n, pt_hit* hits, uint32_t* nbox, uint32_t* ntri)
+{
+    int rc = check_ready(c, false);
+    if (rc != PT_OK) return rc;
+    if (n < 0 || (n > 0 && (!rays || !hits))) { set_error("pt_trace_closest: bad argument"); return PT_ERR_ARG; }
+    if ((nbox == nullptr) != (ntri == nullptr)) { set_error("pt_trace_closest_counted: pass both counter arrays or neither"); return PT_ERR_ARG; }
+    if (n == 0) return PT_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    pt_ray* d_r = nullptr; pt_hit* d_h = nullptr; uint32_t* d_b = nullptr; uint32_t* d_t = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_r, (size_t)n * sizeof(pt_ray)));
+    HIP_TRY(hipMalloc((void**)&d_h, (size_t)n * sizeof(pt_hit)));
+    if (nbox) { HIP_TRY(hipMalloc((void**)&d_b, (size_t)n * 4)); HIP_TRY(hipMalloc((void**)&d_t, (size_t)n * 4)); }
+    HIP_TRY(hipMemcpyAsync(d_r, rays, (size_t)n * sizeof(pt_ray), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    launch_trace_closest(c->scene, d_r, n, d_h, d_b, d_t, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipMemcpyAsync(hits, d_h, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost, c->stream));
+    if (nbox) {
+        HIP_TRY(hipMemcpyAsync(nbox, d_b, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(ntri, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+    }
+    rc = pt_sync(c);
+    (void)hipFree(d_r); (void)hipFree(d_h);
+    if (d_b) (void)hipFree(d_b);
+    if (d_t) (void)hipFree(d_t);
+    return rc;
+}
+
+int pt_trace_closest(pt_ctx* c, const pt_ray* rays, int n, pt_hit* hits) { return pt_trace_closest_counted(c, rays, n, hits, nullptr, nullptr); }
+
+int pt_get_counters(pt_ctx* c, pt_counters* out)
+{
+    if (!c || !out) { set_error("pt_get_counters: null argument"); return PT_ERR_ARG; }
+    *out = c->totals;
+    return PT_OK;
+}
+
+int pt_reset_counters(pt_ctx* c)
+{
+    if (!c) { set_error("null context"); return PT_ERR_ARG; }
+    double ms = c->totals.last_ms;
+    c->totals = pt_counters{};
+    c->totals.last_ms = ms;
+    return PT_OK;
+}
+
+int pt_scene_bytes(pt_ctx* c, uint64_t* node_bytes, uint64_t* tri_bytes)
+{
+    if (!c || !c->have_bvh) { set_error("pt_scene_bytes: no BVH"); return PT_ERR_STATE; }
+    if (node_bytes) *node_bytes = c->n_nodes * sizeof(DNode);
+    if (tri_bytes) *tri_bytes = c->tris.size() * sizeof(DTri);
+    return PT_OK;
+}
+
+// numerics probe: 12 outputs per input pair (see pt_kernels.hip)
+int pt_detmath_probe(pt_ctx* c, const float* x, const float* y, int n, float* out)
+{
+    if (!c || !x || !y || !out || n <= 0) { set_error("pt_detmath_probe: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
+    HIP_TRY(hipMalloc((void**)&dx, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void**)&dy, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void**)&dout, (size_t)n * 48));
+    HIP_TRY(hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dy, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_detmath_probe(dx, dy, n, dout, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 48, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------- host-side producers
+struct pt_host_scene { HostScene s; };
+
+int pt_read_obj(const char* obj_path, const char* model_dir, const char* sub_dir, pt_host_scene** out)
+{
+    if (!obj_path || !out) { set_error("pt_read_obj: null argument"); return PT_ERR_ARG; }
+    pt_host_scene* hs = new (std::nothrow) pt_host_scene();
+    if (!hs) { set_error("out of memory"); return PT_ERR_NOMEM; }
+    int rc = read_obj(obj_path, model_dir, sub_dir, hs->s);
+    if (rc != PT_OK) { delete hs; *out = nullptr; return rc; }
+    *out = hs;
+    return PT_OK;
+}
+void pt_host_scene_free(pt_host_scene* s) { delete s; }
+int pt_host_scene_counts(const pt_host_scene* s, int* n_tri, int* n_mat, int* n_tex)
+{
+    if (!s) { set_error("null scene"); return PT_ERR_ARG; }
+    if (n_tri) *n_tri = (int)s->s.tris.size();
+    if (n_mat) *n_mat = (int)s->s.mats.size();
+    if (n_tex) *n_tex = (int)s->s.textures.size();
+    return PT_OK;
+}
+pt_triangle* pt_host_scene_triangles(pt_host_scene* s) { return s ? s->s.tris.data() : nullptr; }
+int* pt_host_scene_tri_idx(pt_host_scene* s) { return s ? s->s.tri_idx.data() : nullptr; }
+pt_material* pt_host_scene_materials(pt_host_scene* s) { return s ? s->s.mats.data() : nullptr; }
+const char* pt_host_scene_material_name(const pt_host_scene* s, int i)
+{
+    if (!s || i < 0 || i >= (int)s->s.mat_names.size()) return nullptr;
+    return s->s.mat_names[i].c_str();
+}
+int pt_host_scene_texture_info(const pt_host_scene* s, int i, const char** path, int* comps)
+{
+    if (!s || i < 0 || i >= (int)s->s.textures.size()) { set_error("texture index out of range"); return PT_ERR_ARG; }
+    if (path) *path = s->s.textures[i].path.c_str();
+    if (comps) *comps = s->s.textures[i].comps;
+    return PT_OK;
+}
+
+int pt_host_build_bvh(pt_triangle* tris, int* tri_idx, int n_tri, int flavour, pt_bvh_node* nodes_out, int* nodes_used_out)
+{
+    if (!tris || !tri_idx || !nodes_out || !nodes_used_out || n_tri <= 0) { set_error("pt_host_build_bvh: bad argument"); return PT_ERR_ARG; }
+    if (flavour != PT_BVH_REFERENCE) { set_error("pt_host_build_bvh: unknown flavour %d", flavour); return PT_ERR_ARG; }
+    for (int i = 0; i < n_tri; i++) tri_idx[i] = i;
+    return build_bvh_reference(tris, tri_idx, n_tri, nodes_out, nodes_used_out);
+}
+
+int pt_load_hdr(const char* path, float** rgba_out, int* w, int* h)
+{
+    if (!path || !rgba_out || !w || !h) { set_error("pt_load_hdr: null argument"); return PT_ERR_ARG; }
+    return load_hdr(path, rgba_out, w, h);
+}
+int pt_build_env_cdf(const float* rgba, int w, int h, float* cdf_out, float* sum_out)
+{
+    if (!rgba || !cdf_out || !sum_out || w <= 0 || h <= 0) { set_error("pt_build_env_cdf: bad argument"); return PT_ERR_ARG; }
+    build_env_cdf(rgba, w, h, cdf_out, sum_out);
+    return PT_OK;
+}
+void pt_free(void* p) { free(p); }
+
+} // extern "C"

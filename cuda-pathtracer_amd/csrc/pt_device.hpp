@@ -1,0 +1,715 @@
+// Device-side building blocks of the render path for gfx950: vector algebra, Philox stream,
+// software texture sampler, BVH traversal with an LDS-staged stack, material resolve, Disney BSDF,
+// phase function, environment lighting and the per-sample state machine.
+//
+// Arithmetic contract: every expression below is evaluated in the operand types and the order the
+// reference uses ("Cuda Pathtracer/core/CUDA/*"; the function comments give the lines), with FMA
+// contraction disabled for the whole translation unit, IEEE division and square root, and the
+// transcendentals of include/pt_detmath.h.  That makes results reproducible bit for bit on any
+// IEEE machine, which is what the parity tests check.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/pt_capi.h"
+#include "../../include/pt_detmath.h"
+#include "pt_layout.h"
+
+#pragma clang fp contract(off)
+
+namespace ptamd {
+
+#define PT_DEV __device__ __forceinline__
+
+// ---------------------------------------------------------------- vectors (float3_header.cuh:5-123)
+struct F3 { float x, y, z; };
+struct F2 { float x, y; };
+PT_DEV F3 f3(float x, float y, float z) { F3 r; r.x = x; r.y = y; r.z = z; return r; }
+PT_DEV F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
+PT_DEV F3 ld3(const pt_float3& p) { return f3(p.x, p.y, p.z); }
+PT_DEV F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+PT_DEV F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+PT_DEV F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+PT_DEV F3 operator/(F3 a, F3 b) { return f3(a.x / b.x, a.y / b.y, a.z / b.z); }
+PT_DEV F3 operator+(F3 a, float b) { return f3(a.x + b, a.y + b, a.z + b); }
+PT_DEV F3 operator-(F3 a, float b) { return f3(a.x - b, a.y - b, a.z - b); }
+PT_DEV F3 operator*(F3 a, float b) { return f3(a.x * b, a.y * b, a.z * b); }
+PT_DEV F3 operator/(F3 a, float b) { return f3(a.x / b, a.y / b, a.z / b); }
+PT_DEV F3 operator+(float a, F3 b) { return f3(a + b.x, a + b.y, a + b.z); }
+PT_DEV F3 operator-(float a, F3 b) { return f3(a - b.x, a - b.y, a - b.z); }
+PT_DEV F3 operator*(float a, F3 b) { return f3(a * b.x, a * b.y, a * b.z); }
+PT_DEV F3 operator/(float a, F3 b) { return f3(a / b.x, a / b.y, a / b.z); }
+PT_DEV float dot(F3 u, F3 v) { return u.x * v.x + u.y * v.y + u.z * v.z; }
+PT_DEV F3 cross(F3 p, F3 q) { return f3(p.y * q.z - q.y * p.z, p.z * q.x - q.z * p.x, p.x * q.y - q.x * p.y); }
+PT_DEV float sqrt_(float x) { return __builtin_sqrtf(x); }
+PT_DEV float rsqrt_(float x) { return 1.0f / __builtin_sqrtf(x); }
+PT_DEV F3 normalize(F3 a) { float s = rsqrt_(a.x * a.x + a.y * a.y + a.z * a.z); return f3(a.x * s, a.y * s, a.z * s); }
+PT_DEV float length(F3 a) { return sqrt_(a.x * a.x + a.y * a.y + a.z * a.z); }
+PT_DEV float abs_(float x) { return __builtin_fabsf(x); }
+PT_DEV F3 max3(F3 a, F3 b) { return f3(a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z); }
+PT_DEV float getN(F3 v, int n) { return n == 0 ? v.x : (n == 1 ? v.y : v.z); }
+PT_DEV bool finite3(F3 a) { return (a.x - a.x == 0.0f) && (a.y - a.y == 0.0f) && (a.z - a.z == 0.0f); }
+
+// constants.cuh:4-8
+#define PT_PI 3.1415926535f
+#define PT_INV_PI 0.318309f
+#define PT_TWO_PI 6.283184f
+#define PT_INV_TWO_PI 0.159154976203148f
+#define PT_INV_4_PI 0.78539816339744830961566084581988f
+
+// cuda_utility.cuh:7-78
+PT_DEV float clamp_(float a, float l, float h) { return pt_fminf(h, pt_fmaxf(l, a)); }
+PT_DEV float sign_(float x) { if (x == 0) return 0; return x > 0. ? 1. : -1.; }
+PT_DEV float smoothstep_(float e0, float e1, float x) { float t = clamp_((x - e0) / (e1 - e0), 0., 1.); return t * t * (3.0 - 2.0 * t); }
+PT_DEV float mix_(float a, float b, float m) { return a * (1. - m) + b * m; }
+PT_DEV F3 mix_(F3 a, F3 b, float m) { return f3(a.x * (1. - m) + b.x * m, a.y * (1. - m) + b.y * m, a.z * (1. - m) + b.z * m); }
+PT_DEV void onb(F3 N, F3& T, F3& B)
+{
+    F3 up = abs_(N.z) < 0.999 ? f3(0, 0, 1) : f3(1, 0, 0);
+    T = normalize(cross(up, N));
+    B = cross(N, T);
+}
+PT_DEV F3 to_world(F3 X, F3 Y, F3 Z, F3 v) { return v.x * X + v.y * Y + v.z * Z; }
+PT_DEV F3 to_local(F3 X, F3 Y, F3 Z, F3 v) { return f3(dot(v, X), dot(v, Y), dot(v, Z)); }
+PT_DEV F3 ref_if_neg(F3 v, F3 r) { float k = dot(v, r); return k > 0.0f ? v : v - 2.0f * r * k; }
+PT_DEV float power_heuristic(float a, float b) { float t = a * a; return t / (b * b + t); }
+PT_DEV F3 reflect_(F3 I, F3 N) { return I - N * 2.0f * dot(N, I); }
+PT_DEV F3 refract_(F3 I, F3 N, float ior)
+{
+    float k = 1.0 - ior * ior * (1. - dot(N, I) * dot(N, I));
+    if (k < 0.) return f3(0., 0., 0.);
+    return I * ior - N * (ior * dot(N, I) + sqrt_(k));
+}
+PT_DEV F3 pow3(F3 a, float p) { return f3(pt_powf(a.x, p), pt_powf(a.y, p), pt_powf(a.z, p)); }
+
+// ---------------------------------------------------------------- Philox4x32-10 stream
+// curand_init(pixel, 0, 4096*frame) + curand_uniform (cuda_utility.cuh:3-4, pathtracer.cu:560):
+// key (pixel, 0), counter 1024*frame + draw/4, outputs consumed in order, u*2^-32 + 2^-33.
+struct Rng {
+    uint32_t key;
+    uint32_t base;     // counter of draw 0
+    uint32_t draws;    // draws consumed so far
+    uint32_t o0, o1, o2, o3;
+};
+PT_DEV void philox_block(uint32_t key0, uint32_t c0, uint32_t& r0, uint32_t& r1, uint32_t& r2, uint32_t& r3)
+{
+    uint32_t x0 = c0, x1 = 0, x2 = 0, x3 = 0, k0 = key0, k1 = 0;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, x2), lo1 = 0xCD9E8D57u * x2;
+        uint32_t n0 = hi1 ^ x1 ^ k0, n2 = hi0 ^ x3 ^ k1;
+        x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    r0 = x0; r1 = x1; r2 = x2; r3 = x3;
+}
+PT_DEV void rng_seed(Rng& g, uint32_t pixel, uint32_t frame, uint32_t draws)
+{
+    g.key = pixel; g.base = 1024u * frame; g.draws = draws;
+    philox_block(g.key, g.base + (draws >> 2), g.o0, g.o1, g.o2, g.o3);
+}
+PT_DEV float rng_next(Rng& g)
+{
+    uint32_t p = g.draws & 3u;
+    uint32_t v = p == 0 ? g.o0 : (p == 1 ? g.o1 : (p == 2 ? g.o2 : g.o3));
+    g.draws++;
+    if (p == 3) philox_block(g.key, g.base + (g.draws >> 2), g.o0, g.o1, g.o2, g.o3);
+    return (float)v * 2.3283064365386963e-10f + 1.1641532182693481e-10f;
+}
+
+// ---------------------------------------------------------------- software texture unit
+// Wrap addressing, normalized coordinates, bilinear filter with texel centres at +0.5 and fp32
+// weights; stands in for the CUDA texture objects of image_loader.h:37-45 / envmap.cpp:49-57.
+PT_DEV int wrap_(int i, int n) { int m = i % n; return m < 0 ? m + n : m; }
+struct Taps { int i00, i10, i01, i11; float ax, ay, bx, by; };
+PT_DEV Taps tex_taps(int w, int h, float u, float v)
+{
+    if (!(abs_(u) < 65536.0f)) u = 0.0f;
+    if (!(abs_(v) < 65536.0f)) v = 0.0f;
+    float x = u * (float)w - 0.5f;
+    float y = v * (float)h - 0.5f;
+    float fx = __builtin_floorf(x), fy = __builtin_floorf(y);
+    Taps t;
+    t.ax = x - fx; t.ay = y - fy;
+    t.bx = 1.0f - t.ax; t.by = 1.0f - t.ay;
+    int ix = (int)fx, iy = (int)fy;
+    int x0 = wrap_(ix, w), x1 = wrap_(ix + 1, w);
+    int y0 = wrap_(iy, h), y1 = wrap_(iy + 1, h);
+    t.i00 = y0 * w + x0; t.i10 = y0 * w + x1; t.i01 = y1 * w + x0; t.i11 = y1 * w + x1;
+    return t;
+}
+PT_DEV float tex_mix(const Taps& t, float c00, float c10, float c01, float c11)
+{
+    return (c00 * t.bx + c10 * t.ax) * t.by + (c01 * t.bx + c11 * t.ax) * t.ay;
+}
+PT_DEV float4 tex4(const float* texels, int w, int h, float u, float v)
+{
+    Taps t = tex_taps(w, h, u, v);
+    const float4* p = reinterpret_cast<const float4*>(texels);
+    float4 a = p[t.i00], b = p[t.i10], c = p[t.i01], d = p[t.i11];
+    return make_float4(tex_mix(t, a.x, b.x, c.x, d.x), tex_mix(t, a.y, b.y, c.y, d.y),
+                       tex_mix(t, a.z, b.z, c.z, d.z), tex_mix(t, a.w, b.w, c.w, d.w));
+}
+PT_DEV float tex1(const float* texels, int w, int h, float u, float v)
+{
+    Taps t = tex_taps(w, h, u, v);
+    return tex_mix(t, texels[t.i00], texels[t.i10], texels[t.i01], texels[t.i11]);
+}
+
+// ---------------------------------------------------------------- intersection
+// intersectors.cuh:59-71 (boxIntersectF)
+PT_DEV float box_entry(F3 o, F3 inv, const float* bmin, const float* bmax)
+{
+    F3 p0 = -1.0f * (o - ld3(bmin)) * inv;
+    F3 p1 = -1.0f * (o - ld3(bmax)) * inv;
+    float nx = pt_fminf(p0.x, p1.x), ny = pt_fminf(p0.y, p1.y), nz = pt_fminf(p0.z, p1.z);
+    float fx = pt_fmaxf(p0.x, p1.x), fy = pt_fmaxf(p0.y, p1.y), fz = pt_fmaxf(p0.z, p1.z);
+    float tn = pt_fmaxf(pt_fmaxf(nx, ny), nz);
+    float tf = pt_fminf(pt_fminf(fx, fy), fz);
+    if (tf > tn && tf > 0) return tn;
+    return 1e30f;
+}
+
+struct Hit { float t; uint32_t tri; float u, v; };
+#define PT_NO_TRI 0xFFFFFFFFu
+
+// pathtracer.cu:124-139: Moeller-Trumbore with the reference's rejection tests; limit plays hit.t
+PT_DEV bool tri_test(F3 a, F3 e1, F3 e2, F3 o, F3 d, float limit, float& t, float& u, float& v)
+{
+    F3 h = cross(d, e2);
+    float det = dot(e1, h);
+    if (det > -0.0001f && det < 0.0001f) return false;
+    float f = 1.0f / det;
+    F3 s = o - a;
+    u = f * dot(s, h);
+    if (u < 0.f || u > 1.f) return false;
+    F3 q = cross(s, e1);
+    v = f * dot(d, q);
+    if (v < 0.f || u + v > 1.f) return false;
+    t = f * dot(e2, q);
+    if (t < 0.f || t > limit) return false;
+    return true;
+}
+
+// Per-lane traversal stack: the first kLdsDepth entries live in LDS ([entry][lane], so a wave's
+// access is one contiguous 512-byte row), deeper entries spill to private memory.
+constexpr int kLdsDepth = 16;
+constexpr int kSpillDepth = 48;
+struct StackEntry { int ref; float tn; };
+
+template <int BLOCK>
+struct TravStack {
+    uint2* lds;                 // &shared[0][tid]
+    uint2 spill[kSpillDepth];
+    int sp;
+    PT_DEV void init(uint2* shared_base, int tid) { lds = shared_base + tid; sp = 0; }
+    PT_DEV void push(int ref, float tn)
+    {
+        uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
+        if (sp < kLdsDepth) lds[sp * BLOCK] = e;
+        else if (sp - kLdsDepth < kSpillDepth) spill[sp - kLdsDepth] = e;
+        sp++;
+    }
+    PT_DEV StackEntry pop()
+    {
+        sp--;
+        uint2 e = sp < kLdsDepth ? lds[sp * BLOCK] : spill[(sp - kLdsDepth) < kSpillDepth ? (sp - kLdsDepth) : (kSpillDepth - 1)];
+        StackEntry r; r.ref = (int)e.x; r.tn = __uint_as_float(e.y);
+        return r;
+    }
+};
+
+// Closest hit (pathtracer.cu:185-266: BVHIntersect + map). Same visiting order as the reference:
+// the nearer child is entered first, the farther one is deferred together with its entry distance
+// and dropped on pop if that distance no longer beats the current hit. Exact-t ties go to the
+// lowest original triangle index. Rays with a non-finite component miss.
+template <int BLOCK, bool COUNT>
+PT_DEV Hit closest_hit(const DScene& S, F3 o, F3 d, uint2* stack_base, int tid, uint32_t& nbox, uint32_t& ntri)
+{
+    Hit best; best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
+    if (!finite3(o) || !finite3(d)) return best;
+    F3 inv = 1.0f / d;
+    if (COUNT) nbox += 1;
+    float troot = box_entry(o, inv, S.root_min, S.root_max);
+    if (!(troot < best.t)) return best;
+    TravStack<BLOCK> st;
+    st.init(stack_base, tid);
+    int cur = S.root_ref;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
+            float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
+            int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+            float dl = box_entry(o, inv, lmin, lmax);
+            float dr = box_entry(o, inv, rmin, rmax);
+            if (COUNT) nbox += 2;
+            int nearR, farR; float dn, df;
+            if (dl > dr) { nearR = right; dn = dr; farR = left; df = dl; }
+            else         { nearR = left;  dn = dl; farR = right; df = dr; }
+            if (df < best.t) st.push(farR, df);
+            if (dn < best.t) { cur = nearR; continue; }
+        } else {
+            const DTri* tp = S.tris + (~cur);
+            int count = 1;
+            for (int i = 0; i < count; i++) {
+                float4 q0 = tp[i].q0, q1 = tp[i].q1, q2 = tp[i].q2;
+                if (i == 0) count = __float_as_int(q1.w);
+                uint32_t id = __float_as_uint(q0.w);
+                float t, u, v;
+                if (COUNT) ntri += 1;
+                if (!tri_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), o, d, best.t, t, u, v)) continue;
+                if (best.tri != PT_NO_TRI && t == best.t && id > best.tri) continue;
+                best.t = t; best.tri = id; best.u = u; best.v = v;
+            }
+        }
+        bool found = false;
+        while (st.sp > 0) {
+            StackEntry e = st.pop();
+            if (e.tn < best.t) { cur = e.ref; found = true; break; }
+        }
+        if (!found) break;
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------- surface resolve
+struct Mat {
+    F3 base, emis;
+    float rough, aniso, metal, subsurf, sheen, coat, coat_rough, strans, alpha, ior;
+    float G; F3 sigA, sigS;
+};
+struct Surf { float t; F3 n; Mat m; bool hit; bool inside; };
+
+PT_DEV void default_mat(Mat& m)          // structs.cuh:75-94
+{
+    m.base = f3(0, 0, 0); m.emis = f3(0, 0, 0);
+    m.rough = 0.01f; m.aniso = 0; m.metal = 0; m.subsurf = 0; m.sheen = 0; m.coat = 0; m.coat_rough = 0;
+    m.strans = 0; m.alpha = 1.f; m.ior = 1.5f; m.G = 0; m.sigA = f3(0, 0, 0); m.sigS = f3(0, 0, 0);
+}
+
+// pathtracer.cu:140-181: what triangleIntersect does after accepting a hit, evaluated once for the
+// final hit of a query (intermediate accepted hits never reach the caller).
+template <bool COUNT>
+PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& taps)
+{
+    s.t = h.t; s.hit = h.tri != PT_NO_TRI; s.inside = false; s.n = f3(0, 0, 0);
+    default_mat(s.m);
+    if (!s.hit) return;
+    const pt_triangle* T = S.tri_ref + h.tri;
+    const float4* tq = reinterpret_cast<const float4*>(T);      // 112 bytes = 7 x 16
+    float4 t0 = tq[0], t1 = tq[1], t2 = tq[2], t3 = tq[3], t4 = tq[4], t5 = tq[5], t6 = tq[6];
+    F3 a = f3(t0.x, t0.y, t0.z), b = f3(t0.w, t1.x, t1.y), c = f3(t1.z, t1.w, t2.x);
+    F3 nA = f3(t3.x, t3.y, t3.z), nB = f3(t3.w, t4.x, t4.y), nC = f3(t4.z, t4.w, t5.x);
+    F2 tA = {t5.y, t5.z}, tB = {t5.w, t6.x}, tC = {t6.y, t6.z};
+    int mi = __float_as_int(t6.w);
+    const DMat& M = S.mats[mi];
+    const float4* mq = reinterpret_cast<const float4*>(&M);
+    float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3], m4 = mq[4], m5 = mq[5], m6 = mq[6];
+    s.m.base = f3(m0.x, m0.y, m0.z); s.m.emis = f3(m0.w, m1.x, m1.y);
+    s.m.rough = m1.z; s.m.aniso = m1.w; s.m.metal = m2.x; s.m.subsurf = m2.y; s.m.sheen = m2.z; s.m.coat = m2.w;
+    s.m.coat_rough = m3.x; s.m.strans = m3.y; s.m.alpha = m3.z; s.m.ior = m3.w;
+    s.m.G = m4.x; s.m.sigA = f3(m4.y, m4.z, m4.w); s.m.sigS = f3(m5.x, m5.y, m5.z);
+    int tx_d = __float_as_int(m5.w), tx_r = __float_as_int(m6.x), tx_m = __float_as_int(m6.y);
+    int tx_e = __float_as_int(m6.z), tx_n = __float_as_int(m6.w);
+
+    float u = h.u, v = h.v;
+    float w = 1.f - u - v;
+    F3 e1 = b - a, e2 = c - a;
+    F3 ng = normalize(cross(e1, e2));
+    float mult = -sign_(dot(d, ng));
+    s.n = normalize(nA * w + nB * u + nC * v) * mult;
+    float px = tA.x * w + tB.x * u + tC.x * v;
+    float py = tA.y * w + tB.y * u + tC.y * v;
+    if (tx_d) {
+        const DTex tx = S.tex[tx_d - 1];
+        float4 r = tex4(tx.texels, tx.w, tx.h, px, py);
+        s.m.base = f3(r.x, r.y, r.z) * r.w;
+        s.m.alpha = r.w;
+        if (COUNT) taps++;
+    }
+    if (tx_r) { const DTex tx = S.tex[tx_r - 1]; s.m.rough = tex1(tx.texels, tx.w, tx.h, px, py); if (COUNT) taps++; }
+    if (tx_m) { const DTex tx = S.tex[tx_m - 1]; s.m.metal = tex1(tx.texels, tx.w, tx.h, px, py); if (COUNT) taps++; }
+    if (tx_e) { const DTex tx = S.tex[tx_e - 1]; float r = tex1(tx.texels, tx.w, tx.h, px, py); s.m.emis = f3(r, r, r); if (COUNT) taps++; }
+    if (tx_n) {
+        F3 Tn, Bn;
+        onb(s.n, Tn, Bn);
+        const DTex tx = S.tex[tx_n - 1];
+        float4 r = tex4(tx.texels, tx.w, tx.h, px, py);
+        s.n = to_world(Tn, Bn, s.n, f3(r.x * 2.f - 1.f, r.y * 2.f - 1.f, r.z * 2.f - 1.f));
+        if (COUNT) taps++;
+    }
+    s.n = ref_if_neg(s.n, -1.0f * d);
+}
+
+// ---------------------------------------------------------------- Disney BSDF (disney.cuh:29-460)
+namespace disney {
+PT_DEV float luminance(F3 c) { return 0.212671 * c.x + 0.715160 * c.y + 0.072169 * c.z; }
+PT_DEV float schlick_weight(float u) { float m = clamp_(1.0f - u, 0.0f, 1.0f); float m2 = m * m; return m2 * m2 * m; }
+PT_DEV F3 sample_ggx_vndf(F3 V, float ax, float ay, float r1, float r2)          // :41-59
+{
+    F3 Vh = normalize(f3(ax * V.x, ay * V.y, V.z));
+    float lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    F3 T1 = lensq > 0.0 ? f3(-Vh.y, Vh.x, 0.0) * rsqrt_(lensq) : f3(1, 0, 0);
+    F3 T2 = cross(Vh, T1);
+    float r = sqrt_(r1);
+    float phi = 2.0 * PT_PI * r2;
+    float t1 = r * pt_cosf(phi);
+    float t2 = r * pt_sinf(phi);
+    float s = 0.5 * (1.0 + Vh.z);
+    t2 = (1.0 - s) * sqrt_(1.0 - t1 * t1) + s * t2;
+    double rem = 1.0 - t1 * t1 - t2 * t2;
+    F3 Nh = t1 * T1 + t2 * T2 + sqrt_(rem > 0.0 ? rem : 0.0) * Vh;
+    return normalize(f3(ax * Nh.x, ay * Nh.y, pt_fmaxf(0.0, Nh.z)));
+}
+PT_DEV float dielectric_fresnel(float ci, float eta)                             // :61-75
+{
+    float st2 = eta * eta * (1.0f - ci * ci);
+    if (st2 > 1.0f) return 1.0f;
+    double rem = 1.0 - st2;
+    float ct = sqrt_(rem > 0.0 ? rem : 0.0);
+    float rs = (eta * ct - ci) / (eta * ct + ci);
+    float rp = (eta * ci - ct) / (eta * ci + ct);
+    return 0.5f * (rs * rs + rp * rp);
+}
+PT_DEV F3 cosine_hemisphere(float r1, float r2)                                  // :76-85
+{
+    F3 dir;
+    float r = sqrt_(r1);
+    float phi = PT_TWO_PI * r2;
+    dir.x = r * pt_cosf(phi);
+    dir.y = r * pt_sinf(phi);
+    dir.z = sqrt_(pt_fmaxf(0.0, 1.0 - dir.x * dir.x - dir.y * dir.y));
+    return dir;
+}
+PT_DEV float gtr2_aniso(float nh, float hx, float hy, float ax, float ay)        // :103-109
+{
+    float a = hx / ax, b = hy / ay;
+    float c = a * a + b * b + nh * nh;
+    return 1.0 / (PT_PI * ax * ay * c * c);
+}
+PT_DEV float smith_g(float nv, float ag)                                         // :110-115
+{
+    float a = ag * ag, b = nv * nv;
+    return (2.0 * nv) / (nv + sqrt_(a + b - a * b));
+}
+PT_DEV float smith_g_aniso(float nv, float vx, float vy, float ax, float ay)     // :116-122
+{
+    float a = vx * ax, b = vy * ay, c = nv;
+    return (2.0 * nv) / (nv + sqrt_(a * a + b * b + c * c));
+}
+PT_DEV float gtr1(float nh, float a)                                             // :123-130
+{
+    if (a >= 1.0) return PT_INV_PI;
+    float a2 = a * a;
+    float t = 1.0 + (a2 - 1.0) * nh * nh;
+    return (a2 - 1.0) / (PT_PI * pt_logf(a2) * t);
+}
+PT_DEV F3 sample_gtr1(float rgh, float r1, float r2)                             // :132-145
+{
+    float a = pt_fmaxf(0.001, rgh);
+    float a2 = a * a;
+    float phi = r1 * PT_TWO_PI;
+    float ct = sqrt_((1.0 - pt_dm_pow(a2, 1.0 - r2)) / (1.0 - a2));
+    float st = clamp_(pt_dm_sqrt(1.0 - (ct * ct)), 0.0, 1.0);
+    float sp = pt_sinf(phi), cp = pt_cosf(phi);
+    return f3(st * cp, st * sp, ct);
+}
+PT_DEV F3 eval_diffuse(const Mat& m, F3 Csheen, F3 V, F3 L, F3 H, float& pdf)    // :154-181
+{
+    pdf = 0.0;
+    if (L.z <= 0.0) return f3(0, 0, 0);
+    float lh = dot(L, H);
+    float Rr = 2.0f * m.rough * lh * lh;
+    float FL = schlick_weight(L.z), FV = schlick_weight(V.z);
+    float Fretro = Rr * (FL + FV + FL * FV * (Rr - 1.0f));
+    float Fd = (1.0f - 0.5f * FL) * (1.0f - 0.5f * FV);
+    float Fss90 = 0.5 * Rr;
+    float Fss = mix_(1.0f, Fss90, FL) * mix_(1.0f, Fss90, FV);
+    float ss = 1.25f * (Fss * (1.0f / (L.z + V.z) - 0.5f) + 0.5f);
+    float FH = schlick_weight(lh);
+    F3 Fsheen = FH * m.sheen * Csheen;
+    pdf = L.z * PT_INV_PI;
+    return PT_INV_PI * m.base * mix_(Fd + Fretro, ss, m.subsurf) + Fsheen;
+}
+PT_DEV F3 eval_reflection(F3 V, F3 L, F3 H, F3 F, float ax, float ay, float& pdf) // :183-195
+{
+    pdf = 0.0;
+    if (L.z <= 0.0) return f3(0, 0, 0);
+    float D = gtr2_aniso(H.z, H.x, H.y, ax, ay);
+    float G1 = smith_g_aniso(abs_(V.z), V.x, V.y, ax, ay);
+    float G2 = G1 * smith_g_aniso(abs_(L.z), L.x, L.y, ax, ay);
+    pdf = G1 * D / (4.0 * V.z);
+    return F * D * G2 / (float)(4.0 * L.z * V.z);
+}
+PT_DEV F3 eval_refraction(const Mat& m, float eta, F3 V, F3 L, F3 H, F3 F, float ax, float ay, float& pdf) // :197-216
+{
+    pdf = 0.0;
+    if (L.z >= 0.0) return f3(0, 0, 0);
+    float lh = dot(L, H), vh = dot(V, H);
+    float D = gtr2_aniso(H.z, H.x, H.y, ax, ay);
+    float G1 = smith_g_aniso(abs_(V.z), V.x, V.y, ax, ay);
+    float G2 = G1 * smith_g_aniso(abs_(L.z), L.x, L.y, ax, ay);
+    float denom = lh + vh * eta;
+    denom *= denom;
+    float eta2 = eta * eta;
+    float jac = abs_(lh) / denom;
+    pdf = G1 * pt_fmaxf(0.0, vh) * D * jac / V.z;
+    return pow3(m.base, 0.5f) * (1.0f - F) * D * G2 * abs_(vh) * jac * eta2 / abs_(L.z * V.z);
+}
+PT_DEV F3 eval_clearcoat(const Mat& m, F3 V, F3 L, F3 H, float& pdf)             // :218-233
+{
+    pdf = 0.0;
+    if (L.z <= 0.0) return f3(0, 0, 0);
+    float vh = dot(V, H);
+    float F = mix_(0.04, 1.0, schlick_weight(vh));
+    float D = gtr1(H.z, m.coat_rough);
+    float G = smith_g(L.z, 0.25) * smith_g(V.z, 0.25f);
+    float jac = 1.0 / (4.0 * vh);
+    pdf = D * H.z * jac;
+    return f3(F, F, F) * D * G;
+}
+// :234-347 (DisneyEval_2)
+__device__ __noinline__ F3 eval(const Mat& m, bool is_inside, F3 V, F3 N, F3 L, float& pdf)
+{
+    pdf = 0.0;
+    float eta = is_inside ? m.ior : 1.f / m.ior;
+    F3 f = f3(0, 0, 0);
+    float aspect = rsqrt_(1.f - 0.9f * m.aniso);
+    float ax = m.rough * m.rough / aspect;
+    float ay = m.rough * m.rough * aspect;
+    F3 T, B;
+    onb(N, T, B);
+    V = to_local(T, B, N, V);
+    L = to_local(T, B, N, L);
+    F3 H;
+    if (L.z > 0.0) H = normalize(L + V);
+    else H = normalize(L + V * eta);
+    if (H.z < 0.0) H = -1.f * H;
+    float F0 = (1.0 - eta) / (1.0 + eta);                                         // TintColors :92-102
+    F0 *= F0;
+    F3 Cspec0 = F0 * f3(1.f, 1.f, 1.f);
+    F3 Csheen = f3(1.f, 1.f, 1.f);
+    float w_diel = (1.0f - m.metal) * (1.0f - m.strans);
+    float w_metal = m.metal;
+    float w_glass = (1.0f - m.metal) * m.strans;
+    float sw = schlick_weight(V.z);
+    float p_diff = w_diel * luminance(m.base);
+    float p_diel = w_diel * luminance(mix_(Cspec0, f3(1, 1, 1), sw));
+    float p_metal = w_metal * luminance(mix_(m.base, f3(1, 1, 1), sw));
+    float p_glass = w_glass;
+    float p_coat = 0.25f * m.coat;
+    float inv_tot = 1.0f / (p_diff + p_diel + p_metal + p_glass + p_coat);
+    p_diff *= inv_tot; p_diel *= inv_tot; p_metal *= inv_tot; p_glass *= inv_tot; p_coat *= inv_tot;
+    bool refl = L.z * V.z > 0;
+    float tp = 0.0;
+    float vh = abs_(dot(V, H));
+    if (p_diff > 0.0 && refl) {
+        f = f + eval_diffuse(m, Csheen, V, L, H, tp) * w_diel;
+        pdf += tp * p_diff;
+    }
+    if (p_diel > 0.0 && refl) {
+        float F = (dielectric_fresnel(vh, 1.0 / m.ior) - F0) / (1.0 - F0);
+        f = f + eval_reflection(V, L, H, mix_(Cspec0, f3(1, 1, 1), F), ax, ay, tp) * w_diel;
+        pdf += tp * p_diel;
+    }
+    if (p_metal > 0.0 && refl) {
+        F3 F = mix_(m.base, f3(1, 1, 1), schlick_weight(vh));
+        f = f + eval_reflection(V, L, H, F, ax, ay, tp) * w_metal;
+        pdf += tp * p_metal;
+    }
+    if (p_glass > 0.0 && abs_(m.ior - 1.f) > 0.01f) {
+        float F = dielectric_fresnel(vh, eta);
+        if (refl) {
+            f = f + eval_reflection(V, L, H, f3(F, F, F), ax, ay, tp) * w_glass;
+            pdf += tp * p_glass * F;
+        } else {
+            f = f + eval_refraction(m, eta, V, L, H, f3(F, F, F), ax, ay, tp) * w_glass;
+            pdf += tp * p_glass * (1.0f - F);
+        }
+    }
+    if (p_coat > 0.0 && refl) {
+        f = f + eval_clearcoat(m, V, L, H, tp) * 0.25f * m.coat;
+        pdf += tp * p_coat;
+    }
+    return f * abs_(L.z);
+}
+// :348-457 (DisneySample_2 up to the final evaluation). Returns true when the sampled event is the
+// index-matched pass-through (f = 1, pdf = 1); otherwise the caller evaluates the BSDF for L.
+PT_DEV bool sample_dir(const Mat& m, bool is_inside, F3 V, F3 N, F3& L, Rng& rng, bool& inside)
+{
+    float eta = is_inside ? m.ior : 1.f / m.ior;
+    float aspect = rsqrt_(1.f - 0.9f * m.aniso);
+    float ax = m.rough * m.rough / aspect;
+    float ay = m.rough * m.rough * aspect;
+    float r1 = rng_next(rng);
+    float r2 = rng_next(rng);
+    F3 T, B;
+    onb(N, T, B);
+    V = to_local(T, B, N, V);
+    float F0 = (1.0 - eta) / (1.0 + eta);
+    F0 *= F0;
+    F3 Cspec0 = F0 * f3(1.f, 1.f, 1.f);
+    float w_diel = (1.0 - m.metal) * (1.0 - m.strans);
+    float w_metal = m.metal;
+    float w_glass = (1.0 - m.metal) * m.strans;
+    float sw = schlick_weight(V.z);
+    float p_diff = w_diel * luminance(m.base);
+    float p_diel = w_diel * luminance(mix_(Cspec0, f3(1, 1, 1), sw));
+    float p_metal = w_metal * luminance(mix_(m.base, f3(1, 1, 1), sw));
+    float p_glass = w_glass;
+    float p_coat = 0.25 * m.coat;
+    float inv_tot = 1.0 / (p_diff + p_diel + p_metal + p_glass + p_coat);
+    p_diff *= inv_tot; p_diel *= inv_tot; p_metal *= inv_tot; p_glass *= inv_tot; p_coat *= inv_tot;
+    float c0 = p_diff;
+    float c1 = c0 + p_diel;
+    float c2 = c1 + p_metal;
+    float c3 = c2 + p_glass;
+    float r3 = rng_next(rng);
+    if (r3 < c0) {
+        L = cosine_hemisphere(r1, r2);
+    } else if (r3 < c2) {
+        F3 H = sample_ggx_vndf(V, ax, ay, r1, r2);
+        if (H.z < 0.0) H = -1.f * H;
+        L = normalize(reflect_(-1.f * V, H));
+    } else if (r3 < c3) {
+        if (abs_(m.ior - 1.f) <= 0.01f) {
+            L = to_world(T, B, N, -1.f * V);
+            inside = !inside;
+            return true;
+        }
+        F3 H = sample_ggx_vndf(V, ax, ay, r1, r2);
+        float F = dielectric_fresnel(abs_(dot(V, H)), eta);
+        if (H.z < 0.0) H = -1.f * H;
+        r3 = (r3 - c2) / (c3 - c2);
+        if (r3 < F) {
+            L = normalize(reflect_(-1.f * V, H));
+        } else {
+            L = normalize(refract_(-1.f * V, H, eta));
+            inside = !inside;
+        }
+    } else {
+        F3 H = sample_gtr1(m.coat_rough, r1, r2);
+        if (H.z < 0.0) H = -1.f * H;
+        L = normalize(reflect_(-1.f * V, H));
+    }
+    L = to_world(T, B, N, L);
+    return false;
+}
+} // namespace disney
+
+// ---------------------------------------------------------------- phase function (phase_function.cu:5-20)
+PT_DEV float eval_hg(float mu, float g)
+{
+    return PT_INV_4_PI * (1. - g * g) / (pt_powf(1. + g * g - 2.0f * g * mu, 1.5f));
+}
+PT_DEV F3 sample_hg(F3 d, float g, Rng& rng)
+{
+    float xi = rng_next(rng);
+    float t = (1.f - g * g) / (1.f - g + 2.0f * g * xi);
+    float mu = (0.5f / g) * ((1.f + g * g) - t * t);
+    float phi = PT_TWO_PI * rng_next(rng);
+    float st = sqrt_(pt_fmaxf(0.f, 1.f - mu * mu));
+    F3 T, B;
+    onb(d, T, B);
+    return normalize(st * pt_cosf(phi) * T + st * pt_sinf(phi) * B + mu * d);
+}
+
+// ---------------------------------------------------------------- sky (envmap_cuda.cu:12-74, pathtracer.cu:340-363)
+PT_DEV float4 eval_envmap(const DScene& S, F3 dir)
+{
+    float theta = pt_acosf(clamp_(dir.y, -1.0f, 1.0f));
+    float u = (PT_PI + pt_atan2f(dir.z, dir.x)) * PT_INV_TWO_PI;
+    float v = theta * PT_INV_PI;
+    float4 r = tex4(S.env_rgba, S.env_w, S.env_h, u, v);
+    float pdf = disney::luminance(f3(r.x, r.y, r.z)) / S.env_sum;
+    return make_float4(r.x, r.y, r.z, (pdf * S.env_w * S.env_h) / (PT_TWO_PI * PT_PI * pt_sinf(theta)));
+}
+template <bool COUNT>
+PT_DEV F2 env_search(const DScene& S, float xi, uint32_t& taps)
+{
+    int lower = 0, upper = S.env_h - 1;
+    while (lower < upper) {
+        int mid = (lower + upper) >> 1;
+        float c = tex1(S.env_cdf, S.env_w, S.env_h, 1.f, (float)mid / (float)S.env_h);
+        if (COUNT) taps++;
+        if (xi < c) upper = mid; else lower = mid + 1;
+    }
+    int y = (int)clamp_((float)lower, 0.f, (float)(S.env_h - 1));
+    lower = 0; upper = S.env_w - 1;
+    while (lower < upper) {
+        int mid = (lower + upper) >> 1;
+        float c = tex1(S.env_cdf, S.env_w, S.env_h, (float)mid / (float)S.env_w, (float)y / (float)S.env_h);
+        if (COUNT) taps++;
+        if (xi < c) upper = mid; else lower = mid + 1;
+    }
+    int x = (int)clamp_((float)lower, 0.f, (float)(S.env_w - 1));
+    F2 uv = {(float)x / (float)S.env_w, (float)y / (float)S.env_h};
+    return uv;
+}
+// returns direction + pdf; color receives the radiance
+template <bool COUNT>
+PT_DEV float4 sample_envmap(const DScene& S, F3& color, Rng& rng, uint32_t& taps)
+{
+    F2 uv = env_search<COUNT>(S, rng_next(rng) * S.env_sum, taps);
+    float4 r = tex4(S.env_rgba, S.env_w, S.env_h, uv.x, uv.y);
+    if (COUNT) taps++;
+    color = f3(r.x, r.y, r.z);
+    float pdf = disney::luminance(color) / S.env_sum;
+    float phi = uv.x * PT_TWO_PI;
+    float theta = uv.y * PT_PI;
+    float sn = pt_sinf(theta);
+    if (sn == 0.f) pdf = 0.f;
+    return make_float4(-sn * pt_cosf(phi), pt_cosf(theta), -sn * pt_sinf(phi), (pdf * S.env_w * S.env_h) / (PT_TWO_PI * PT_PI * sn));
+}
+PT_DEV float sky_hg(float g, float c) { float gg = g * g; return (1. - gg) / pt_dm_pow(1. + gg - 2. * g * c, 1.5); }
+PT_DEV float sky_rayleigh(float u) { return 0.75 * (1. + clamp_(u * u, 0., 1.)); }
+__device__ __noinline__ F3 sky_gradient(F3 rd, F3 sun)
+{
+    F3 sunColor = mix_(f3(1., 0.9, 0.8), f3(1., 0.2, 0.), pt_dm_exp(-abs_(sun.y) * 5.));
+    float c0 = dot(rd, sun);
+    float blend = smoothstep_(-1., 0.6, c0);
+    F3 day = mix_(f3(0.3, 0.6, 1.) * 0.7 * sky_rayleigh(c0), f3(0.9, 0.95, 1.), pt_dm_exp(-abs_(rd.y) * 5.));
+    F3 even = mix_(f3(0.3, 0.6, 1.) * 0.7, mix_(f3(0.2, 0.3, 0.4), f3(1., 0.2, 0.), blend), pt_dm_exp(-abs_(rd.y) * 5.));
+    F3 sunDisk = (float)(0.02 / length(rd - sun)) * sunColor;
+    F3 night = f3(0.05, 0.1, 0.2) + clamp_(0.02 / length(rd + sun), 0., 1.) * f3(0.7, 0.8, 1.) * 0.6;
+    F3 dayF = mix_(day, even, pt_dm_exp(-abs_(sun.y) * 5.)) + sunDisk;
+    float earth = smoothstep_(-0.02, 0.02, rd.y) * 0.5 + 0.5;
+    float mieM = 1. - abs_(dot(sun, f3(0., 1., 0.))) + 0.3;
+    return mix_(night, dayF + sky_hg(0.6, c0) * sunColor * 0.3 * mieM, smoothstep_(-0.2, 0.0, sun.y)) * earth * 0.75;
+}
+
+// ---------------------------------------------------------------- tonemap (tonemapping.cuh:17-63, pathtracer.cu:588-599)
+PT_DEV F3 agx_tonemap(F3 x)
+{
+    const float min_ev = -12.47393f, max_ev = 4.026069f;
+    x = f3(0.842479062253094f * x.x + 0.0423282422610123f * x.y + 0.0423756549057051f * x.z,
+           0.0784335999999992f * x.x + 0.878468636469772f * x.y + 0.0784336f * x.z,
+           0.0792237451477643f * x.x + 0.0791661274605434f * x.y + 0.879142973793104f * x.z);
+    x = f3(clamp_(pt_log2f(x.x), min_ev, max_ev), clamp_(pt_log2f(x.y), min_ev, max_ev), clamp_(pt_log2f(x.z), min_ev, max_ev));
+    x = (x - min_ev) / (max_ev - min_ev);
+    F3 x2 = x * x;
+    F3 x4 = x2 * x2;
+    x = 15.5f * x4 * x2 - 40.14f * x4 * x + 31.96f * x4 - 6.868f * x2 * x + 0.4298f * x2 + 0.1191f * x - 0.00232f;
+    const F3 lw = f3(0.2126f, 0.7152f, 0.0722f);
+    float luma = dot(lw, x);
+    F3 offset = f3(0.f, 0.f, 0.f), slope = f3(1.f, 1.f, 1.f);
+    float power = 1.35f, sat = 1.4f;
+    x = pow3(x * slope + offset, power);
+    x = luma + sat * (x - luma);
+    return f3(1.19687900512017f * x.x - 0.0528968517574562f * x.y - 0.0529716355144438f * x.z,
+              -0.0980208811401368f * x.x + 1.15190312990417f * x.y - 0.0980434501171241f * x.z,
+              -0.0990297440797205f * x.x - 0.0989611768448433f * x.y + 1.15107367264116f * x.z);
+}
+PT_DEV uint8_t to_byte(float c)
+{
+    float s = c * 255;
+    if (!(s == s)) return 0;
+    if (s <= -2147483648.0f) return 0;
+    if (s >= 2147483648.0f) return 255;
+    int v = (int)s;
+    return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+} // namespace ptamd

@@ -1,0 +1,154 @@
+// HIP kernels of the render path (gfx950) and their launchers.
+#include <hip/hip_runtime.h>
+#include "pt_path.hpp"
+#include "pt_launch.h"
+
+#pragma clang fp contract(off)
+
+namespace ptamd {
+
+// ---------------------------------------------------------------- closest-hit batch
+// One ray per lane, 256 lanes per workgroup; the traversal stack of each lane sits in LDS.
+template <bool COUNT>
+__global__ __launch_bounds__(256) void trace_closest_kernel(DScene S, const pt_ray* __restrict__ rays, int n,
+                                                            pt_hit* __restrict__ hits, uint32_t* __restrict__ nbox_out,
+                                                            uint32_t* __restrict__ ntri_out)
+{
+    __shared__ uint2 stack[kLdsDepth * 256];
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float4* rp = reinterpret_cast<const float4*>(rays + i);
+    float4 r0 = rp[0], r1 = rp[1];
+    uint32_t nb = 0, nt = 0;
+    Hit h = closest_hit<256, COUNT>(S, f3(r0.x, r0.y, r0.z), f3(r1.x, r1.y, r1.z), stack, threadIdx.x, nb, nt);
+    pt_hit out; out.t = h.t; out.tri = h.tri;
+    hits[i] = out;
+    if (COUNT) { nbox_out[i] = nb; ntri_out[i] = nt; }
+}
+
+void launch_trace_closest(const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, uint32_t* nbox_dev, uint32_t* ntri_dev, hipStream_t stream)
+{
+    if (n <= 0) return;
+    dim3 grid((n + 255) / 256), block(256);
+    if (nbox_dev && ntri_dev)
+        hipLaunchKernelGGL(trace_closest_kernel<true>, grid, block, 0, stream, S, rays_dev, n, hits_dev, nbox_dev, ntri_dev);
+    else
+        hipLaunchKernelGGL(trace_closest_kernel<false>, grid, block, 0, stream, S, rays_dev, n, hits_dev, nbox_dev, ntri_dev);
+}
+
+// ---------------------------------------------------------------- whole-sample kernel
+// One pixel per lane, an 8x8 pixel tile per wave (pathtracer.cu:604 uses the same tile), frames
+// [frame_begin, frame_end) in order so the accumulator sees the same additions as a frame loop.
+// Each lane runs the sample state machine; all its rays (camera, bounce, shadow segments) go
+// through one traversal call site.
+template <bool COUNT>
+__global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera cam, int frame_begin, int frame_end,
+                                                            float* __restrict__ accum, DCounters* __restrict__ ctr)
+{
+    __shared__ uint2 stack[kLdsDepth * 64];
+    int tiles_x = (cam.W + 7) >> 3;
+    int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    int x = tx * 8 + (threadIdx.x & 7), y = ty * 8 + (threadIdx.x >> 3);
+    if (x >= cam.W || y >= cam.H) return;
+    size_t pix = (size_t)(x + y * cam.W) * 3;
+    F3 acc = f3(accum[pix], accum[pix + 1], accum[pix + 2]);
+    Tally tl = {0, 0, 0, 0, 0, 0};
+    uint32_t nsamples = 0;
+    for (int frame = frame_begin; frame < frame_end; frame++) {
+        Path P;
+        begin_sample(P, cam, x, y, frame);
+        nsamples++;
+        F3 color = f3(0.f, 0.f, 0.f);
+        if (!cam.is_rendering) {
+            // preview: pathtracer.cu:504-525
+            Hit h = closest_hit<64, COUNT>(S, P.o, P.d, stack, threadIdx.x, tl.box, tl.tri);
+            if (COUNT) tl.rays++;
+            Surf info;
+            resolve_hit<COUNT>(S, h, P.d, info, tl.taps);
+            if (info.hit) {
+                float NoV = pt_fmaxf(dot(P.d * -1.0f, info.n), 0.f);
+                color = NoV * info.m.base;
+            } else if (S.sky_mode == PT_SKY_SUNSKY) {
+                color = sky_gradient(P.d, ld3(S.sun));
+            } else {
+                float4 e = eval_envmap(S, P.d);
+                color = f3(e.x, e.y, e.z);
+            }
+        } else {
+            while (P.state != ST_DONE) {
+                if (P.state == ST_AFTER) { after_light<COUNT>(S, cam, P, tl); continue; }
+                bool shadow = P.state == ST_SHADOW;
+                F3 ro = shadow ? P.so : P.o;
+                F3 rd = shadow ? P.sd : P.d;
+                Hit h = closest_hit<64, COUNT>(S, ro, rd, stack, threadIdx.x, tl.box, tl.tri);
+                if (COUNT) tl.rays++;
+                Surf info;
+                resolve_hit<COUNT>(S, h, rd, info, tl.taps);
+                if (shadow) on_shadow_hit<COUNT>(S, cam, P, info, tl);
+                else on_path_hit<COUNT>(S, cam, P, info, tl);
+            }
+            F3 c = f3(0.f, 0.f, 0.f);
+            if (P.ch == 0) c.x = P.result; else if (P.ch == 1) c.y = P.result; else if (P.ch == 2) c.z = P.result;
+            color = c * 3.f;
+        }
+        F3 c0 = max3(color, f3(0.f, 0.f, 0.f));
+        acc = acc + c0;
+    }
+    accum[pix] = acc.x; accum[pix + 1] = acc.y; accum[pix + 2] = acc.z;
+    if (COUNT) {
+        atomicAdd(&ctr->rays, (unsigned long long)tl.rays);
+        atomicAdd(&ctr->samples, (unsigned long long)nsamples);
+        atomicAdd(&ctr->box_tests, (unsigned long long)tl.box);
+        atomicAdd(&ctr->tri_tests, (unsigned long long)tl.tri);
+        atomicAdd(&ctr->shade_vertices, (unsigned long long)tl.verts);
+        atomicAdd(&ctr->env_samples, (unsigned long long)tl.envs);
+        atomicAdd(&ctr->tex_taps, (unsigned long long)tl.taps);
+    }
+}
+
+void launch_render_samples(const DScene& S, const DCamera& cam, int frame_begin, int frame_end, float* accum_dev, DCounters* ctr_dev, hipStream_t stream)
+{
+    int tiles = ((cam.W + 7) / 8) * ((cam.H + 7) / 8);
+    dim3 grid(tiles), block(64);
+    if (ctr_dev)
+        hipLaunchKernelGGL(render_samples_kernel<true>, grid, block, 0, stream, S, cam, frame_begin, frame_end, accum_dev, ctr_dev);
+    else
+        hipLaunchKernelGGL(render_samples_kernel<false>, grid, block, 0, stream, S, cam, frame_begin, frame_end, accum_dev, ctr_dev);
+}
+
+// ---------------------------------------------------------------- display resolve
+// pathtracer.cu:588-599: accum / frames -> AgX -> RGBA8
+__global__ __launch_bounds__(256) void resolve_display_kernel(const float* __restrict__ accum, int n_pixels, float frames, uint8_t* __restrict__ rgba)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pixels) return;
+    F3 c = f3(accum[3 * i], accum[3 * i + 1], accum[3 * i + 2]) / frames;
+    c = agx_tonemap(c);
+    uchar4 o = make_uchar4(to_byte(c.x), to_byte(c.y), to_byte(c.z), 255);
+    reinterpret_cast<uchar4*>(rgba)[i] = o;
+}
+
+void launch_resolve_display(const float* accum_dev, int n_pixels, int n_frames, uint8_t* rgba_dev, hipStream_t stream)
+{
+    dim3 grid((n_pixels + 255) / 256), block(256);
+    hipLaunchKernelGGL(resolve_display_kernel, grid, block, 0, stream, accum_dev, n_pixels, (float)n_frames, rgba_dev);
+}
+
+// ---------------------------------------------------------------- numerics probe
+// Evaluates the pinned transcendentals on the device so tests can compare bits with the host.
+__global__ void detmath_probe_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, float* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float a = x[i], b = y[i];
+    float* o = out + (size_t)i * 12;
+    o[0] = pt_sinf(a); o[1] = pt_cosf(a); o[2] = pt_expf(a); o[3] = pt_logf(a); o[4] = pt_log2f(a);
+    o[5] = pt_powf(a, b); o[6] = pt_acosf(a); o[7] = pt_atan2f(a, b);
+    o[8] = 1.0f / a; o[9] = __builtin_sqrtf(a); o[10] = a / b; o[11] = (float)pt_dm_pow((double)a, (double)b);
+}
+void launch_detmath_probe(const float* x_dev, const float* y_dev, int n, float* out_dev, hipStream_t stream)
+{
+    hipLaunchKernelGGL(detmath_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x_dev, y_dev, n, out_dev);
+}
+
+} // namespace ptamd

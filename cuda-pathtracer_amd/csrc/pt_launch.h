@@ -1,0 +1,11 @@
+// Kernel launchers (defined in pt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "pt_layout.h"
+
+namespace ptamd {
+void launch_trace_closest(const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, uint32_t* nbox_dev, uint32_t* ntri_dev, hipStream_t stream);
+void launch_render_samples(const DScene& S, const DCamera& cam, int frame_begin, int frame_end, float* accum_dev, DCounters* ctr_dev, hipStream_t stream);
+void launch_resolve_display(const float* accum_dev, int n_pixels, int n_frames, uint8_t* rgba_dev, hipStream_t stream);
+void launch_detmath_probe(const float* x_dev, const float* y_dev, int n, float* out_dev, hipStream_t stream);
+}

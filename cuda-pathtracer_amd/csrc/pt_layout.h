@@ -1,0 +1,67 @@
+// Device-memory layouts of the render path, shared by the host-side uploaders and the kernels.
+#pragma once
+#include <stdint.h>
+#include <hip/hip_runtime.h>
+#include "../../include/pt_capi.h"
+
+namespace ptamd {
+
+// ---------------------------------------------------------------- device data layout
+// Interior node, 64 bytes = four 16-byte loads: both children's boxes and their references.
+// ref >= 0: interior node index; ref < 0: leaf whose first triangle record is ~ref (the record
+// carries the leaf's triangle count).
+struct __attribute__((aligned(64))) DNode {
+    float lmin[3], lmax[3];
+    float rmin[3], rmax[3];
+    int left, right;
+    int pad0, pad1;
+};
+static_assert(sizeof(DNode) == 64, "node must be one 64-byte record");
+
+// Triangle record for intersection, 48 bytes = three 16-byte loads, stored in leaf order.
+// q0 = (a.xyz, original index), q1 = (b-a, triangles in this leaf [first record only]), q2 = (c-a, 0)
+struct __attribute__((aligned(16))) DTri { float4 q0, q1, q2; };
+static_assert(sizeof(DTri) == 48, "triangle record must be 48 bytes");
+
+// Material record for shading, 128 bytes. Texture slots are 1-based indices into the texture table.
+struct __attribute__((aligned(16))) DMat {
+    float base[3]; float emis[3];
+    float rough, aniso, metal, subsurf, sheen, coat, coat_rough, strans, alpha, ior;
+    float G; float sigA[3]; float sigS[3];
+    int tex_diffuse, tex_rough, tex_metal, tex_emis, tex_normal;
+    int pad[4];
+};
+static_assert(sizeof(DMat) == 128, "material record must be 128 bytes");
+
+struct DTex { const float* texels; int w, h, comps, pad; };
+
+struct DScene {
+    const DNode* nodes;
+    const DTri* tris;             // leaf order
+    const pt_triangle* tri_ref;   // original order, reference layout (shading attributes)
+    const DMat* mats;
+    const DTex* tex;
+    const float* env_rgba;
+    const float* env_cdf;
+    int env_w, env_h;
+    float env_sum;
+    int sky_mode;
+    float sun[3];
+    float root_min[3], root_max[3];
+    int root_ref;
+    int n_tris;
+};
+
+struct DCamera {
+    float origin[3], ww[3], uu[3], vv[3];
+    float fov, focal, dof;
+    int W, H;
+    int is_rendering;
+    int max_bounces;
+};
+
+struct DCounters {
+    unsigned long long rays, samples, box_tests, tri_tests, shade_vertices, env_samples, tex_taps;
+};
+
+} // namespace ptamd

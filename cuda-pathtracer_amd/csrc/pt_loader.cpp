@@ -1,0 +1,375 @@
+// Host-side asset ingest for the render path: triangulated OBJ + MTL with the PBR keys, Radiance
+// RGBE environment maps and their sampling table, PNG screenshots.
+//
+// Behaviour follows the reference loaders so that a scene loads to the same arrays:
+//   OBJ/MTL  "Cuda Pathtracer/core/file_reader.h:35-425"
+//   HDR      "Cuda Pathtracer/core/hdr_loader.h:47-281"
+//   CDF      "Cuda Pathtracer/core/envmap.cpp:11-28"
+// including its quirks (single-space token splitting, the face layout chosen by whether any vn/vt
+// line was seen so far, vertex indices above the triangle count reset to 0, usemtl names read from
+// column 7, unknown material names mapped to material 0, vertices scaled by 100).  Where the
+// reference would read out of bounds or throw, this loader reports an error instead.
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <fstream>
+#include <string>
+#include <vector>
+#include <zlib.h>
+#include "pt_internal.h"
+
+namespace ptamd {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...)
+{
+    va_list ap; va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+void default_material(pt_material& m)     // structs.cuh:75-94
+{
+    memset(&m, 0, sizeof(m));
+    m.roughness = 0.01f;
+    m.ior = 1.5f;
+    m.alpha = 1.f;
+}
+
+namespace {
+
+// One text line with the reference's token rule (file_reader.h:35-46): a token runs from a start
+// column to the next occurrence of a stop character; the cursor is left ON the stop character (or on
+// the last column when the stop character does not occur; untouched when the start is past the end).
+struct Line {
+    const std::string& s;
+    int end = 0;
+    explicit Line(const std::string& str) : s(str) {}
+    std::string upto(int first, char stop)
+    {
+        std::string out;
+        int n = (int)s.size();
+        for (int i = first; i < n; i++) {
+            end = i;
+            if (s[i] == stop) return out;
+            out.push_back(s[i]);
+        }
+        return out;
+    }
+    std::string next(char stop) { return upto(end + 1, stop); }
+    std::string key() { end = 0; return upto(0, ' '); }
+};
+
+bool to_float(const std::string& tok, float& v)
+{
+    const char* c = tok.c_str();
+    char* e = nullptr;
+    v = strtof(c, &e);
+    return e != c;
+}
+bool to_int(const std::string& tok, int& v)
+{
+    const char* c = tok.c_str();
+    char* e = nullptr;
+    long l = strtol(c, &e, 10);
+    v = (int)l;
+    return e != c;
+}
+
+struct MtlParse {
+    HostScene& sc;
+    std::string dir;
+    int request_texture(const std::string& rel, int comps)
+    {
+        sc.textures.push_back(TextureRequest{dir + rel, comps});
+        return (int)sc.textures.size();      // handle placeholder = index + 1
+    }
+};
+
+bool read3(Line& ln, pt_float3& v)
+{
+    return to_float(ln.next(' '), v.x) && to_float(ln.next(' '), v.y) && to_float(ln.next('\n'), v.z);
+}
+
+// file_reader.h:48-208
+int read_mtl(const std::string& path, const std::string& tex_dir, HostScene& sc)
+{
+    std::ifstream f(path);
+    if (!f.is_open()) { set_error("cannot open material library %s", path.c_str()); return PT_ERR_IO; }
+    MtlParse mp{sc, tex_dir};
+    pt_material cur; default_material(cur);
+    std::string cur_name;
+    std::string text;
+    int lineno = 0;
+    while (std::getline(f, text)) {
+        lineno++;
+        Line ln(text);
+        std::string k = ln.key();
+        bool ok = true;
+        if (k == "newmtl") {
+            if (!cur_name.empty()) { sc.mats.push_back(cur); sc.mat_names.push_back(cur_name); default_material(cur); }
+            cur_name = ln.next('\n');
+        } else if (k == "Kd") { ok = read3(ln, cur.baseColor); }
+        else if (k == "Ke") { ok = read3(ln, cur.emissive); }
+        else if (k == "d") { float v; ok = to_float(ln.next('\n'), v); if (ok) cur.specTrans = (float)(1. - v); }
+        else if (k == "Tf") { pt_float3 v; ok = read3(ln, v); if (ok) cur.medium.sigmaA = pt_float3{1.f - v.x, 1.f - v.y, 1.f - v.z}; }
+        else if (k == "Ts") { ok = read3(ln, cur.medium.sigmaS); }
+        else if (k == "Pg") { ok = to_float(ln.next(' '), cur.medium.G); }
+        else if (k == "Ni") { ok = to_float(ln.next(' '), cur.ior); }
+        else if (k == "Pr") { ok = to_float(ln.next('\n'), cur.roughness); }
+        else if (k == "Pm") { ok = to_float(ln.next('\n'), cur.metallic); }
+        else if (k == "Ps") { ok = to_float(ln.next('\n'), cur.sheen); }
+        else if (k == "aniso") { ok = to_float(ln.next('\n'), cur.anisotropic); }
+        else if (k == "map_Kd") { cur.diffuseTexture = mp.request_texture(ln.next('\n'), 4); cur.useTexture = 1; }
+        else if (k == "map_Pr") { cur.roughnessTexture = mp.request_texture(ln.next('\n'), 1); cur.use_mapPr = 1; }
+        else if (k == "map_Pm") { cur.metallicTexture = mp.request_texture(ln.next('\n'), 1); cur.use_mapPm = 1; }
+        else if (k == "map_Bump") {
+            ln.next(' '); ln.next(' ');                      // skips "-bm <scale>" (file_reader.h:165-166)
+            cur.normalTexture = mp.request_texture(ln.next('\n'), 4); cur.use_mapNor = 1;
+        }
+        else if (k == "map_Ke") { cur.emissiveTexture = mp.request_texture(ln.next('\n'), 1); cur.use_mapKe = 1; }
+        if (!ok) { set_error("%s:%d: malformed number", path.c_str(), lineno); return PT_ERR_IO; }
+    }
+    sc.mats.push_back(cur);
+    sc.mat_names.push_back(cur_name);
+    return PT_OK;
+}
+
+inline pt_float3 unit3(pt_float3 a)       // float3_header.cuh:72-76 with rsqrtf = 1/sqrtf
+{
+    float s = 1.0f / sqrtf(a.x * a.x + a.y * a.y + a.z * a.z);
+    return pt_float3{a.x * s, a.y * s, a.z * s};
+}
+
+struct Corner { int v[3]; };
+
+} // namespace
+
+// file_reader.h:217-425
+int read_obj(const char* obj_path, const char* model_dir, const char* sub_dir, HostScene& sc)
+{
+    const float size = 100.f;
+    std::ifstream f(obj_path);
+    if (!f.is_open()) { set_error("cannot open model %s", obj_path); return PT_ERR_IO; }
+    std::string mdir = model_dir ? model_dir : "";
+    if (!mdir.empty() && mdir.back() != '/') mdir.push_back('/');
+    std::string sdir = sub_dir ? sub_dir : "";
+    std::vector<pt_float3> pts, nrm;
+    std::vector<pt_float2> uvs;
+    std::vector<Corner> fpos, fnrm, fuv;
+    std::vector<int> fmat;
+    bool anyN = false, anyT = false;
+    int cur_mat = 0;
+    std::string text;
+    int lineno = 0;
+    auto idx_tok = [](const std::string& tok, int& dst) { int v; if (!tok.empty() && to_int(tok, v)) dst = v - 1; };
+    while (std::getline(f, text)) {
+        lineno++;
+        Line ln(text);
+        std::string k = ln.key();
+        if (k == "f") {
+            Corner p{{0, 0, 0}}, t{{0, 0, 0}}, n{{0, 0, 0}};
+            if (anyN) {
+                idx_tok(ln.next('/'), p.v[0]); idx_tok(ln.next('/'), t.v[0]); idx_tok(ln.next(' '), n.v[0]);
+                idx_tok(ln.next('/'), p.v[1]); idx_tok(ln.next('/'), t.v[1]); idx_tok(ln.next(' '), n.v[1]);
+                idx_tok(ln.next('/'), p.v[2]); idx_tok(ln.next('/'), t.v[2]); idx_tok(ln.next('\n'), n.v[2]);
+            } else if (anyT) {
+                idx_tok(ln.next('/'), p.v[0]); idx_tok(ln.next(' '), t.v[0]);
+                idx_tok(ln.next('/'), p.v[1]); idx_tok(ln.next(' '), t.v[1]);
+                idx_tok(ln.next('/'), p.v[2]); idx_tok(ln.next('\n'), t.v[2]);
+            } else {
+                idx_tok(ln.next(' '), p.v[0]); idx_tok(ln.next(' '), p.v[1]); idx_tok(ln.next('\n'), p.v[2]);
+            }
+            fpos.push_back(p); fnrm.push_back(n); fuv.push_back(t); fmat.push_back(cur_mat);
+        } else if (k == "v") {
+            pt_float3 p;
+            if (!read3(ln, p)) { set_error("%s:%d: malformed vertex", obj_path, lineno); return PT_ERR_IO; }
+            pts.push_back(pt_float3{p.x * size + 0.f, p.y * size + 0.f, p.z * size + 0.f});
+        } else if (k == "vn") {
+            pt_float3 p;
+            if (!read3(ln, p)) { set_error("%s:%d: malformed normal", obj_path, lineno); return PT_ERR_IO; }
+            nrm.push_back(p); anyN = true;
+        } else if (k == "vt") {
+            pt_float2 c;
+            if (!(to_float(ln.next(' '), c.x) && to_float(ln.next('\n'), c.y))) { set_error("%s:%d: malformed texcoord", obj_path, lineno); return PT_ERR_IO; }
+            uvs.push_back(c); anyT = true;
+        } else if (k == "usemtl") {
+            std::string name = ln.upto(7, '\n');
+            cur_mat = 0;
+            for (size_t i = 0; i < sc.mat_names.size(); i++) if (sc.mat_names[i] == name) { cur_mat = (int)i; break; }
+        } else if (k == "mtllib") {
+            std::string lib = ln.next('\n');
+            // the reference replaces the material list on every mtllib (file_reader.h:185-193)
+            sc.mats.clear(); sc.mat_names.clear();
+            int rc = read_mtl(mdir + sdir + lib, mdir + sdir, sc);
+            if (rc != PT_OK) return rc;
+        }
+    }
+    int nbTri = (int)fpos.size();
+    if (nbTri == 0) { set_error("%s: no faces", obj_path); return PT_ERR_IO; }
+    if (sc.mats.empty()) { pt_material m; default_material(m); sc.mats.push_back(m); sc.mat_names.push_back(""); }
+    sc.tris.assign(nbTri, pt_triangle{});
+    sc.tri_idx.resize(nbTri);
+    for (int i = 0; i < nbTri; i++) {
+        int a[3], n[3], t[3];
+        for (int c = 0; c < 3; c++) {
+            a[c] = fpos[i].v[c]; n[c] = fnrm[i].v[c]; t[c] = fuv[i].v[c];
+            if (a[c] > nbTri) a[c] = 0;                                   // file_reader.h:386-397
+            if (n[c] < 0) n[c] = (int)nrm.size() - n[c] - 1;              // :398-400
+            if (a[c] < 0) a[c] = (int)pts.size() - a[c] - 1;              // :402-404
+            if (a[c] < 0 || a[c] >= (int)pts.size()) { set_error("%s: face %d references vertex %d of %zu", obj_path, i, a[c] + 1, pts.size()); return PT_ERR_IO; }
+            if (anyN && (n[c] < 0 || n[c] >= (int)nrm.size())) { set_error("%s: face %d references normal %d of %zu", obj_path, i, n[c] + 1, nrm.size()); return PT_ERR_IO; }
+            if (anyT && (t[c] < 0 || t[c] >= (int)uvs.size())) { set_error("%s: face %d references texcoord %d of %zu", obj_path, i, t[c] + 1, uvs.size()); return PT_ERR_IO; }
+        }
+        pt_triangle& T = sc.tris[i];
+        memset(&T, 0, sizeof(T));
+        T.a = pts[a[0]]; T.b = pts[a[1]]; T.c = pts[a[2]];
+        T.matIndex = fmat[i];
+        if (anyN) { T.nA = unit3(nrm[n[0]]); T.nB = unit3(nrm[n[1]]); T.nC = unit3(nrm[n[2]]); }
+        if (anyT) { T.tA = uvs[t[0]]; T.tB = uvs[t[1]]; T.tC = uvs[t[2]]; }
+        sc.tri_idx[i] = i;
+    }
+    return PT_OK;
+}
+
+// ---------------------------------------------------------------- Radiance RGBE, hdr_loader.h:47-281
+namespace {
+bool starts(const char* line, const char* id, const char** rest)
+{
+    size_t l = strlen(id);
+    if (strncmp(line, id, l) != 0) return false;
+    *rest = line + l;
+    return true;
+}
+bool read_flat(unsigned char* buf, unsigned len, FILE* fp) { return fread(buf, 4, len, fp) == len; }
+bool read_rle(unsigned char* buf, unsigned len, FILE* fp)      // hdr_loader.h:124-194
+{
+    int c = fgetc(fp);
+    if (c == EOF) return false;
+    if (c != 2) { ungetc(c, fp); return read_flat(buf, len, fp); }
+    buf[1] = (unsigned char)fgetc(fp);
+    buf[2] = (unsigned char)fgetc(fp);
+    c = fgetc(fp);
+    if (buf[1] != 2 || (buf[2] & 128)) { buf[0] = 2; buf[3] = (unsigned char)c; return read_flat(buf + 4, len - 1, fp); }
+    unsigned l = (unsigned)buf[2] << 8 | (unsigned)c;
+    if (l != len) return false;
+    for (unsigned comp = 0; comp < 4; comp++) {
+        for (unsigned pos = 0; pos < len;) {
+            int num = fgetc(fp);
+            if (num == EOF) return false;
+            if (num > 128) {
+                num &= 127;
+                int val = fgetc(fp);
+                if (val == EOF || pos + num > len) return false;
+                for (int j = 0; j < num; j++) buf[(pos++) * 4 + comp] = (unsigned char)val;
+            } else {
+                if (pos + num > len) return false;
+                for (int j = 0; j < num; j++) {
+                    int val = fgetc(fp);
+                    if (val == EOF) return false;
+                    buf[(pos++) * 4 + comp] = (unsigned char)val;
+                }
+            }
+        }
+    }
+    return true;
+}
+}
+
+int load_hdr(const char* path, float** rgba_out, int* w_out, int* h_out)
+{
+    *rgba_out = nullptr; *w_out = *h_out = 0;
+    FILE* fp = fopen(path, "rb");
+    if (!fp) { set_error("cannot open %s", path); return PT_ERR_IO; }
+    char line[2048];
+    unsigned rx = 0, ry = 0;
+    if (!fgets(line, sizeof(line), fp) || (line[0] != '#' && line[1] != '?')) { fclose(fp); set_error("%s: not a Radiance file", path); return PT_ERR_IO; }
+    for (;;) {
+        if (!fgets(line, sizeof(line), fp)) { fclose(fp); set_error("%s: truncated header", path); return PT_ERR_IO; }
+        if (line[0] == '#') continue;
+        const char* rest;
+        if (starts(line, "FORMAT=", &rest)) {
+            if (strncmp(rest, "32-bit_rle_xyze", 15) != 0 && strncmp(rest, "32-bit_rle_rgbe", 15) != 0) { fclose(fp); set_error("%s: unknown FORMAT", path); return PT_ERR_IO; }
+        } else if (line[0] == '-' || line[0] == '+') {
+            const char* x = strchr(line, 'X');
+            const char* y = strchr(line, 'Y');
+            if (!x || x <= line || sscanf(x + 1, "%u", &rx) != 1 || !y || y <= line || sscanf(y + 1, "%u", &ry) != 1) { fclose(fp); set_error("%s: bad resolution line", path); return PT_ERR_IO; }
+            break;
+        }
+    }
+    if (rx == 0 || ry == 0 || (uint64_t)rx * ry > (1ull << 30)) { fclose(fp); set_error("%s: bad size", path); return PT_ERR_IO; }
+    float* px = (float*)calloc((size_t)rx * ry, 4 * sizeof(float));
+    unsigned char* buf = (unsigned char*)malloc((size_t)rx * 4);
+    if (!px || !buf) { free(px); free(buf); fclose(fp); set_error("out of memory"); return PT_ERR_NOMEM; }
+    const bool rle = !(rx < 8 || rx > 0x7fff);
+    for (unsigned j = 0; j < ry; j++) {
+        bool ok = rle ? read_rle(buf, rx, fp) : read_flat(buf, rx, fp);
+        if (!ok) { free(px); free(buf); fclose(fp); set_error("%s: pixel data truncated", path); return PT_ERR_IO; }
+        for (unsigned i = 0; i < rx; i++) {
+            const unsigned char* e = buf + 4 * i;
+            float* o = px + 4 * ((size_t)j * rx + i);
+            if (e[3] == 0) { o[0] = o[1] = o[2] = 0.f; }
+            else {
+                uint32_t bits = (uint32_t)(((int)e[3] - 9) << 23) & 0x7f800000u;   // hdr_loader.h:210
+                float sc; memcpy(&sc, &bits, 4);
+                o[0] = (float)(e[0] + 0.5f) * sc; o[1] = (float)(e[1] + 0.5f) * sc; o[2] = (float)(e[2] + 0.5f) * sc;
+            }
+        }
+    }
+    free(buf); fclose(fp);
+    *rgba_out = px; *w_out = (int)rx; *h_out = (int)ry;
+    return PT_OK;
+}
+
+// envmap.cpp:7-28: running sum of luminance over all texels, row-major
+void build_env_cdf(const float* rgba, int w, int h, float* cdf, float* sum)
+{
+    size_t n = (size_t)w * h;
+    float run = 0.f;
+    for (size_t i = 0; i < n; i++) {
+        float wgt = (float)(0.212671 * rgba[4 * i] + 0.715160 * rgba[4 * i + 1] + 0.072169 * rgba[4 * i + 2]);
+        run = i == 0 ? wgt : run + wgt;
+        cdf[i] = run;
+    }
+    *sum = cdf[n - 1];
+}
+
+// main.cpp:96-114 saves the RGBA8 display buffer as PNG through SFML; this writes the same pixels
+// with zlib (8-bit RGBA, no interlace, filter 0 on every row).
+int save_png(const char* path, const uint8_t* rgba, int w, int h)
+{
+    if (!path || !rgba || w <= 0 || h <= 0) { set_error("save_png: bad argument"); return PT_ERR_ARG; }
+    std::vector<uint8_t> raw((size_t)h * ((size_t)w * 4 + 1));
+    for (int y = 0; y < h; y++) {
+        raw[(size_t)y * (w * 4 + 1)] = 0;
+        memcpy(&raw[(size_t)y * (w * 4 + 1) + 1], rgba + (size_t)y * w * 4, (size_t)w * 4);
+    }
+    uLongf clen = compressBound(raw.size());
+    std::vector<uint8_t> comp(clen);
+    if (compress2(comp.data(), &clen, raw.data(), raw.size(), 6) != Z_OK) { set_error("save_png: deflate failed"); return PT_ERR_IO; }
+    FILE* fp = fopen(path, "wb");
+    if (!fp) { set_error("cannot write %s", path); return PT_ERR_IO; }
+    auto be32 = [](uint8_t* p, uint32_t v) { p[0] = v >> 24; p[1] = v >> 16; p[2] = v >> 8; p[3] = v; };
+    auto chunk = [&](const char* type, const uint8_t* data, uint32_t len) {
+        uint8_t hdr[8]; be32(hdr, len); memcpy(hdr + 4, type, 4);
+        fwrite(hdr, 1, 8, fp);
+        if (len) fwrite(data, 1, len, fp);
+        uLong crc = crc32(0L, (const Bytef*)type, 4);
+        if (len) crc = crc32(crc, data, len);
+        uint8_t c[4]; be32(c, (uint32_t)crc); fwrite(c, 1, 4, fp);
+    };
+    const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    fwrite(sig, 1, 8, fp);
+    uint8_t ihdr[13]; be32(ihdr, (uint32_t)w); be32(ihdr + 4, (uint32_t)h);
+    ihdr[8] = 8; ihdr[9] = 6; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0;
+    chunk("IHDR", ihdr, 13);
+    chunk("IDAT", comp.data(), (uint32_t)clen);
+    chunk("IEND", nullptr, 0);
+    fclose(fp);
+    return PT_OK;
+}
+
+} // namespace ptamd

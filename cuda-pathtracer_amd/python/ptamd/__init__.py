@@ -1,0 +1,3 @@
+from .types import *  # noqa
+from . import lib  # noqa
+from .lib import Renderer, HostScene, PtError  # noqa

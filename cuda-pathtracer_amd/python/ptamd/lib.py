@@ -1,0 +1,269 @@
+"""ctypes binding of libptamd.so, the C-ABI declared in include/pt_capi.h.
+
+This is plumbing for tests and the benchmark: every call goes straight to the shared library.
+There is no Python or CPU fallback; a missing library or a missing GPU raises.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+from .types import TRI_DTYPE, NODE_DTYPE, MAT_DTYPE, RAY_DTYPE, HIT_DTYPE, Params, Counters, Float3
+
+_PKG = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+LIB_PATH = os.path.join(_PKG, 'libptamd.so')
+
+PT_SKY_ENVMAP, PT_SKY_SUNSKY = 0, 1
+PT_BVH_REFERENCE = 0
+
+EXPORTS = [
+    'pt_last_error', 'pt_create', 'pt_destroy', 'pt_set_stream', 'pt_init', 'pt_clear_accum', 'pt_upload_triangles',
+    'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_upload_texture', 'pt_upload_envmap',
+    'pt_set_sky_mode', 'pt_set_max_bounces', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
+    'pt_accum_device_ptr', 'pt_resolve_display', 'pt_save_png', 'pt_trace_closest', 'pt_trace_closest_dev',
+    'pt_trace_closest_counted', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_scene_bytes',
+    'pt_detmath_probe', 'pt_read_obj', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
+    'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
+    'pt_host_build_bvh', 'pt_load_hdr', 'pt_build_env_cdf', 'pt_free', 'pt_camera_basis',
+]
+
+_lib = None
+
+
+class PtError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise PtError('%s is missing: build it with `make -C cuda-pathtracer_amd` (or __graft_entry__.build())' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.pt_last_error.restype = C.c_char_p
+        L.pt_host_scene_triangles.restype = C.c_void_p
+        L.pt_host_scene_tri_idx.restype = C.c_void_p
+        L.pt_host_scene_materials.restype = C.c_void_p
+        L.pt_host_scene_material_name.restype = C.c_char_p
+        L.pt_free.argtypes = [C.c_void_p]
+        L.pt_destroy.argtypes = [C.c_void_p]
+        L.pt_host_scene_free.argtypes = [C.c_void_p]
+        for n in ('pt_host_scene_triangles', 'pt_host_scene_tri_idx', 'pt_host_scene_materials'):
+            getattr(L, n).argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise PtError('libptamd error %d: %s' % (rc, lib().pt_last_error().decode('utf-8', 'replace')))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+# ------------------------------------------------------------------ host-side producers (no GPU)
+class HostScene:
+    """Result of pt_read_obj: triangles, index array, materials and the texture files the MTL names."""
+
+    def __init__(self, obj_path, model_dir, sub_dir=''):
+        h = C.c_void_p()
+        check(lib().pt_read_obj(obj_path.encode(), model_dir.encode(), sub_dir.encode(), C.byref(h)))
+        try:
+            nt, nm, nx = C.c_int(), C.c_int(), C.c_int()
+            check(lib().pt_host_scene_counts(h, C.byref(nt), C.byref(nm), C.byref(nx)))
+            self.tris = np.ctypeslib.as_array(C.cast(lib().pt_host_scene_triangles(h), C.POINTER(C.c_uint8)),
+                                              (nt.value * TRI_DTYPE.itemsize,)).view(TRI_DTYPE).copy()
+            self.tri_idx = np.ctypeslib.as_array(C.cast(lib().pt_host_scene_tri_idx(h), C.POINTER(C.c_int32)), (nt.value,)).copy()
+            self.mats = np.ctypeslib.as_array(C.cast(lib().pt_host_scene_materials(h), C.POINTER(C.c_uint8)),
+                                              (nm.value * MAT_DTYPE.itemsize,)).view(MAT_DTYPE).copy()
+            self.mat_names = [lib().pt_host_scene_material_name(h, C.c_int(i)).decode('utf-8', 'replace') for i in range(nm.value)]
+            self.texture_requests = []
+            for i in range(nx.value):
+                path, comps = C.c_char_p(), C.c_int()
+                check(lib().pt_host_scene_texture_info(h, C.c_int(i), C.byref(path), C.byref(comps)))
+                self.texture_requests.append((path.value.decode(), comps.value))
+        finally:
+            lib().pt_host_scene_free(h)
+
+
+def host_build_bvh(tris, flavour=PT_BVH_REFERENCE):
+    """buildBVH on host arrays: returns (nodes[:used], tri_idx); tris['origin'] is filled in place."""
+    n = len(tris)
+    assert tris.dtype == TRI_DTYPE and tris.flags['C_CONTIGUOUS']
+    nodes = np.zeros(2 * n - 1 + 1, dtype=NODE_DTYPE)
+    idx = np.arange(n, dtype=np.int32)
+    used = C.c_int()
+    check(lib().pt_host_build_bvh(_p(tris), _p(idx), C.c_int(n), C.c_int(flavour), _p(nodes), C.byref(used)))
+    return nodes[:used.value].copy(), idx
+
+
+def load_hdr(path):
+    ptr, w, h = C.c_void_p(), C.c_int(), C.c_int()
+    check(lib().pt_load_hdr(path.encode(), C.byref(ptr), C.byref(w), C.byref(h)))
+    try:
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), (h.value, w.value, 4)).copy()
+    finally:
+        lib().pt_free(ptr)
+    return a
+
+
+def build_env_cdf(rgba):
+    rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+    h, w, _ = rgba.shape
+    cdf = np.zeros((h, w), dtype=np.float32)
+    s = C.c_float()
+    check(lib().pt_build_env_cdf(_p(rgba), C.c_int(w), C.c_int(h), _p(cdf), C.byref(s)))
+    return cdf, s.value
+
+
+def camera_basis(params):
+    ww, uu, vv = Float3(), Float3(), Float3()
+    check(lib().pt_camera_basis(C.byref(params), C.byref(ww), C.byref(uu), C.byref(vv)))
+    f = lambda v: np.array([v.x, v.y, v.z], dtype=np.float32)
+    return f(ww), f(uu), f(vv)
+
+
+def save_png(path, rgba):
+    rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
+    h, w, _ = rgba.shape
+    check(lib().pt_save_png(path.encode(), _p(rgba), C.c_int(w), C.c_int(h)))
+
+
+# ------------------------------------------------------------------ device context
+class Renderer:
+    """One pt_ctx bound to one GPU."""
+
+    def __init__(self, device=0):
+        self.h = C.c_void_p()
+        check(lib().pt_create(C.byref(self.h), C.c_int(device)))
+        self.params = None
+
+    def close(self):
+        if self.h:
+            lib().pt_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle):
+        check(lib().pt_set_stream(self.h, C.c_void_p(stream_handle)))
+
+    def init(self, params):
+        self.params = params
+        check(lib().pt_init(self.h, C.byref(params)))
+
+    def upload_texture(self, texels):
+        t = np.ascontiguousarray(texels, dtype=np.float32)
+        if t.ndim == 2:
+            t = t[:, :, None]
+        h, w, c = t.shape
+        handle = C.c_uint64()
+        check(lib().pt_upload_texture(self.h, _p(t), C.c_int(w), C.c_int(h), C.c_int(c), C.byref(handle)))
+        return handle.value
+
+    def upload_scene(self, tris, mats, tri_idx=None, nodes=None):
+        tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
+        mats = np.ascontiguousarray(mats, dtype=MAT_DTYPE)
+        idx = None if tri_idx is None else np.ascontiguousarray(tri_idx, dtype=np.int32)
+        check(lib().pt_upload_triangles(self.h, _p(idx), _p(tris), C.c_int(len(tris))))
+        check(lib().pt_upload_materials(self.h, _p(mats), C.c_int(len(mats))))
+        if nodes is None:
+            check(lib().pt_build_bvh(self.h, C.c_int(PT_BVH_REFERENCE)))
+        else:
+            nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
+            check(lib().pt_upload_bvh(self.h, _p(nodes), C.c_int(0), C.c_int(len(nodes)), C.c_int(len(tris))))
+
+    def upload_envmap(self, rgba, cdf, total, params=None):
+        rgba = np.ascontiguousarray(rgba, dtype=np.float32)
+        cdf = np.ascontiguousarray(cdf, dtype=np.float32)
+        h, w, _ = rgba.shape
+        check(lib().pt_upload_envmap(self.h, _p(rgba), _p(cdf), C.c_int(w), C.c_int(h), C.c_float(total),
+                                     C.byref(params) if params is not None else None))
+
+    def set_sky_mode(self, mode):
+        check(lib().pt_set_sky_mode(self.h, C.c_int(mode)))
+
+    def set_max_bounces(self, n):
+        check(lib().pt_set_max_bounces(self.h, C.c_int(n)))
+
+    def enable_counters(self, on=True):
+        check(lib().pt_enable_counters(self.h, C.c_int(1 if on else 0)))
+
+    def clear_accum(self):
+        check(lib().pt_clear_accum(self.h))
+
+    def render(self, params, frame_begin, frame_end, sync=True):
+        check(lib().pt_render_headless(self.h, C.byref(params), C.c_int(frame_begin), C.c_int(frame_end)))
+        if sync:
+            self.sync()
+
+    def render_frame(self, params):
+        W, H = params.windowSize.x, params.windowSize.y
+        buf = np.zeros((H, W, 4), dtype=np.uint8)
+        params.pixelBuffer = buf.ctypes.data
+        check(lib().pt_render_frame(self.h, C.byref(params)))
+        params.pixelBuffer = None
+        return buf
+
+    def sync(self):
+        check(lib().pt_sync(self.h))
+
+    def read_accum(self):
+        W, H = self.params.windowSize.x, self.params.windowSize.y
+        out = np.zeros((H, W, 3), dtype=np.float32)
+        check(lib().pt_read_accum(self.h, _p(out)))
+        return out
+
+    def write_accum(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        check(lib().pt_write_accum(self.h, _p(a)))
+
+    def accum_device_ptr(self):
+        p = C.c_void_p()
+        check(lib().pt_accum_device_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def resolve_display(self, n_frames):
+        W, H = self.params.windowSize.x, self.params.windowSize.y
+        out = np.zeros((H, W, 4), dtype=np.uint8)
+        check(lib().pt_resolve_display(self.h, C.c_int(n_frames), _p(out)))
+        return out
+
+    def trace_closest(self, rays, counted=False):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(len(rays), dtype=HIT_DTYPE)
+        if counted:
+            nb = np.zeros(len(rays), dtype=np.uint32)
+            nt = np.zeros(len(rays), dtype=np.uint32)
+            check(lib().pt_trace_closest_counted(self.h, _p(rays), C.c_int(len(rays)), _p(hits), _p(nb), _p(nt)))
+            return hits, nb, nt
+        check(lib().pt_trace_closest(self.h, _p(rays), C.c_int(len(rays)), _p(hits)))
+        return hits
+
+    def trace_closest_dev(self, rays_ptr, n, hits_ptr):
+        check(lib().pt_trace_closest_dev(self.h, C.c_void_p(rays_ptr), C.c_int(n), C.c_void_p(hits_ptr)))
+
+    def counters(self):
+        c = Counters()
+        check(lib().pt_get_counters(self.h, C.byref(c)))
+        return {n: getattr(c, n) for n, _ in Counters._fields_}
+
+    def reset_counters(self):
+        check(lib().pt_reset_counters(self.h))
+
+    def scene_bytes(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        check(lib().pt_scene_bytes(self.h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def detmath_probe(self, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        out = np.zeros((len(x), 12), dtype=np.float32)
+        check(lib().pt_detmath_probe(self.h, _p(x), _p(y), C.c_int(len(x)), _p(out)))
+        return out

@@ -1,0 +1,195 @@
+/*
+ * pt_capi.h — C-ABI of the MI355X-native render hot path.
+ *
+ * Every entry point replaces one function of the reference's device boundary
+ * (namespace pathtracer, "Cuda Pathtracer/core/CUDA/pathtracer.cuh:48-54") or
+ * one of the host-side producers the reference application calls directly
+ * (file_reader.h, BVH_builder.cpp, envmap.cpp, image_loader.h).  The POD
+ * structs keep the reference's field order and byte layout
+ * (core/CUDA/utility/structs.cuh) so host arrays produced by either side can
+ * be handed to the other unchanged.
+ *
+ * Conventions: every function returns PT_OK (0) or a negative error code;
+ * pt_last_error() returns a thread-local message for the last failure.
+ * Pointers are host pointers unless the parameter name ends in _dev.
+ * A context is bound to one HIP device; calls on one context must not overlap.
+ */
+#ifndef PT_CAPI_H
+#define PT_CAPI_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_OK            0
+#define PT_ERR_ARG      -1
+#define PT_ERR_HIP      -2
+#define PT_ERR_STATE    -3
+#define PT_ERR_IO       -4
+#define PT_ERR_NOMEM    -5
+
+/* sky selection (pathtracer.cu:346-380 holds both an envmap and a sun/sky model) */
+#define PT_SKY_ENVMAP    0
+#define PT_SKY_SUNSKY    1
+
+/* BVH build flavours for pt_host_build_bvh / pt_build_bvh */
+#define PT_BVH_REFERENCE 0   /* identical tree to BVH_builder.cpp:12-128, built with binned sweeps */
+
+typedef struct pt_float2 { float x, y; } pt_float2;
+typedef struct pt_float3 { float x, y, z; } pt_float3;
+typedef struct pt_int2 { int x, y; } pt_int2;
+
+/* structs.cuh:111-128 — 112 bytes */
+typedef struct pt_triangle {
+    pt_float3 a, b, c, origin;
+    pt_float3 nA, nB, nC;
+    pt_float2 tA, tB, tC;
+    int matIndex;
+} pt_triangle;
+
+/* structs.cuh:130-137 — 32 bytes */
+typedef struct pt_bvh_node {
+    pt_float3 aabbMin, aabbMax;
+    int leftFirst, triCount;
+} pt_bvh_node;
+
+/* structs.cuh:36-44 — 28 bytes */
+typedef struct pt_medium {
+    float G;
+    pt_float3 sigmaA;
+    pt_float3 sigmaS;
+} pt_medium;
+
+/* structs.cuh:45-95 — 176 bytes. Texture fields hold handles returned by
+ * pt_upload_texture (0 = none), in place of cudaTextureObject_t. */
+typedef struct pt_material {
+    pt_float3 baseColor;
+    pt_float3 emissive;
+    float roughness;
+    float anisotropic;
+    float metallic;
+    float subsurface;
+    float sheen;
+    float clearcoat;
+    float clearcoatRoughness;
+    float specTrans;
+    float alpha;
+    float ior;
+    pt_medium medium;
+    uint32_t _pad0;
+    uint64_t diffuseTexture;   uint8_t useTexture; uint8_t _p1[7];
+    uint64_t roughnessTexture; uint8_t use_mapPr;  uint8_t _p2[7];
+    uint64_t metallicTexture;  uint8_t use_mapPm;  uint8_t _p3[7];
+    uint64_t emissiveTexture;  uint8_t use_mapKe;  uint8_t _p4[7];
+    uint64_t normalTexture;    uint8_t use_mapNor; uint8_t _p5[7];
+} pt_material;
+
+/* structs.cuh:149-181 (kernelParams) — 152 bytes */
+typedef struct pt_params {
+    pt_int2 windowSize;
+    pt_float3 rayOrigin;
+    pt_float3 rayDirectionZ;
+    pt_float3 cameraAngle;
+    float cameraSpeed;
+    pt_float3 sunDirection;
+    float focalDistance;
+    float DOF_strenght;
+    float fov;
+    int frameIndex;
+    uint32_t _pad0;
+    uint8_t* pixelBuffer;
+    uint8_t isRendering; uint8_t _p1[3];
+    float envmap_sum;
+    pt_int2 envMap_size;
+    uint64_t cubeMap;
+    uint64_t envMap_cdf;
+    pt_float3 mult;
+    float gamma;
+    float contrast;
+    float saturation;
+    float exposure;
+    uint32_t _pad1;
+} pt_params;
+
+/* one closest-hit query: pathtracer.cu:236-266 (map) */
+typedef struct pt_ray { pt_float3 o; float _pad0; pt_float3 d; float _pad1; } pt_ray;      /* 32 bytes */
+typedef struct pt_hit { float t; uint32_t tri; } pt_hit;   /* tri = original triangle index, 0xFFFFFFFF and t = 1e10 on a miss */
+
+typedef struct pt_counters {
+    uint64_t rays;          /* closest-hit queries: camera, bounce and shadow-walk segments */
+    uint64_t samples;       /* renderPixel evaluations */
+    uint64_t box_tests;     /* ray/box tests, 1 + 2 per expanded interior node per ray */
+    uint64_t tri_tests;     /* ray/triangle tests */
+    uint64_t shade_vertices;/* surface or medium events shaded */
+    uint64_t env_samples;   /* envmap importance samples drawn */
+    uint64_t tex_taps;      /* bilinear texture lookups */
+    double   last_ms;       /* device time of the last render / trace call (HIP events) */
+} pt_counters;
+
+typedef struct pt_ctx pt_ctx;
+
+const char* pt_last_error(void);
+
+/* ---- device boundary: pathtracer.cuh:48-54 ---- */
+int pt_create(pt_ctx** out, int device_id);
+void pt_destroy(pt_ctx* ctx);                                           /* endCuda, pathtracer.cu:101 */
+int pt_set_stream(pt_ctx* ctx, void* hip_stream);                       /* launch on a caller-owned stream (NULL = the context's own) */
+int pt_init(pt_ctx* ctx, const pt_params* params);                      /* initCuda, pathtracer.cu:37: sizes accum/display from windowSize */
+int pt_upload_triangles(pt_ctx* ctx, const int* tri_idx, const pt_triangle* tris, int n_tri);   /* transferTriangles, pathtracer.cu:66 */
+int pt_upload_materials(pt_ctx* ctx, const pt_material* mats, int n_mat);                       /* transfertMaterials, pathtracer.cu:87 */
+int pt_upload_bvh(pt_ctx* ctx, const pt_bvh_node* nodes, int root_idx, int nodes_used, int n_tri); /* transfertBVH, pathtracer.cu:92; re-flattened on upload */
+int pt_build_bvh(pt_ctx* ctx, int flavour);                             /* buildBVH (BVH_builder.cpp:115) on the uploaded triangles, then upload */
+int pt_render_frame(pt_ctx* ctx, pt_params* params);                    /* render, pathtracer.cu:602: one sample per pixel, RGBA8 into params->pixelBuffer */
+
+/* ---- textures and sky: image_loader.h:5-89, envmap.cpp:37-94 ---- */
+int pt_upload_texture(pt_ctx* ctx, const float* texels, int w, int h, int comps, uint64_t* handle_out); /* comps 4 = genTexture, 1 = genTexture_float; rows already V-flipped */
+int pt_upload_envmap(pt_ctx* ctx, const float* rgba, const float* cdf, int w, int h, float sum, pt_params* params_io); /* generateCUDAenvmap + transfertToParams */
+int pt_set_sky_mode(pt_ctx* ctx, int mode);
+
+/* ---- headless rendering (replaces the window loop, main.cpp:247-296) ---- */
+int pt_set_max_bounces(pt_ctx* ctx, int max_bounces);                   /* pathtracer.cu:405 hard-codes 512 */
+int pt_render_headless(pt_ctx* ctx, const pt_params* params, int frame_begin, int frame_end); /* frames [begin,end): accum as pathtracer.cu:583-586, first frame overwrites */
+int pt_read_accum(pt_ctx* ctx, float* rgb_out);                         /* 3*W*H floats */
+int pt_accum_device_ptr(pt_ctx* ctx, float** accum_dev_out);            /* device address of the fp32 accumulator (for collectives) */
+int pt_resolve_display(pt_ctx* ctx, int n_frames, uint8_t* rgba_out);   /* accum/n -> AgX -> RGBA8 (pathtracer.cu:588-599); rgba_out may be NULL */
+int pt_save_png(const char* path, const uint8_t* rgba, int w, int h);   /* saveToFile, main.cpp:96-114 */
+
+/* ---- closest-hit batch (test and measurement entry) ---- */
+int pt_trace_closest(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hits_out);
+int pt_trace_closest_dev(pt_ctx* ctx, const pt_ray* rays_dev, int n, pt_hit* hits_dev);
+int pt_trace_closest_counted(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hits_out, uint32_t* box_tests_out, uint32_t* tri_tests_out);
+
+int pt_get_counters(pt_ctx* ctx, pt_counters* out);
+int pt_enable_counters(pt_ctx* ctx, int on);                            /* instrumented kernels (slower); off by default */
+
+/* ---- host-side producers (no GPU needed) ---- */
+typedef struct pt_host_scene pt_host_scene;
+/* readObjFile, file_reader.h:217; model_dir replaces the hard-wired "assets/models/" prefix (file_reader.h:51,147) */
+int pt_read_obj(const char* obj_path, const char* model_dir, const char* sub_dir, pt_host_scene** out);
+void pt_host_scene_free(pt_host_scene* s);
+int pt_host_scene_counts(const pt_host_scene* s, int* n_tri, int* n_mat, int* n_tex);
+pt_triangle* pt_host_scene_triangles(pt_host_scene* s);
+int* pt_host_scene_tri_idx(pt_host_scene* s);
+pt_material* pt_host_scene_materials(pt_host_scene* s);
+const char* pt_host_scene_material_name(const pt_host_scene* s, int i);
+/* texture i (0-based) as requested by the MTL: path, kind (4 = RGBA, 1 = R). Material texture fields hold i+1 until uploaded. */
+int pt_host_scene_texture_info(const pt_host_scene* s, int i, const char** path, int* comps);
+
+/* buildBVH, BVH_builder.cpp:115: fills tris[i].origin, permutes tri_idx, writes up to 2n-1 nodes */
+int pt_host_build_bvh(pt_triangle* tris, int* tri_idx, int n_tri, int flavour, pt_bvh_node* nodes_out, int* nodes_used_out);
+
+/* load_hdr_float4 (hdr_loader.h:253) + envMap::buildCDF (envmap.cpp:11-28). Caller frees with pt_free. */
+int pt_load_hdr(const char* path, float** rgba_out, int* w, int* h);
+int pt_build_env_cdf(const float* rgba, int w, int h, float* cdf_out, float* sum_out);
+void pt_free(void* p);
+
+/* camera basis from cameraAngle (pathtracer.cu:568-571), computed once on the host */
+int pt_camera_basis(const pt_params* params, pt_float3* ww, pt_float3* uu, pt_float3* vv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PT_CAPI_H */
