@@ -1297,6 +1297,18 @@ void orc_sky_gradient(const float d[3], const float sun[3], float out[3])
     out[0] = c.x; out[1] = c.y; out[2] = c.z;
 }
 
+// host evaluation of the pinned transcendentals, same 12 outputs per input as the device probe
+void orc_detmath_probe(const float* x, const float* y, int n, float* out)
+{
+    for (int i = 0; i < n; i++) {
+        float a = x[i], b = y[i];
+        float* o = out + (size_t)i * 12;
+        o[0] = pt_sinf(a); o[1] = pt_cosf(a); o[2] = pt_expf(a); o[3] = pt_logf(a); o[4] = pt_log2f(a);
+        o[5] = pt_powf(a, b); o[6] = pt_acosf(a); o[7] = pt_atan2f(a, b);
+        o[8] = 1.0f / a; o[9] = __builtin_sqrtf(a); o[10] = a / b; o[11] = (float)pt_dm_pow((double)a, (double)b);
+    }
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP

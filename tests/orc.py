@@ -199,3 +199,11 @@ def camera_basis(params):
 
 def max_threads():
     return lib().orc_max_threads()
+
+
+def detmath_probe(x, y):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    out = np.zeros((len(x), 12), dtype=np.float32)
+    lib().orc_detmath_probe(_p(x), _p(y), C.c_int(len(x)), _p(out))
+    return out

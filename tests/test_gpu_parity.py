@@ -1,0 +1,194 @@
+"""GPU parity tests: the HIP path (through the C-ABI) against the CPU oracle on the same inputs.
+Bars: closest hits bit-exact (triangle id and t bits); radiance bit-exact as well, because both sides
+evaluate the same pinned arithmetic (the contract allows 1e-4 relative; the tests hold the tighter bar
+and report the worst relative error if it is ever missed)."""
+import numpy as np
+import pytest
+
+import ptamd
+from ptamd import scenes, lib
+import orc
+import util
+from util import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1e-6)))
+
+
+def test_detmath_bits_match_host():
+    rng = np.random.default_rng(7)
+    n = 1 << 18
+    x = np.concatenate([rng.uniform(-20, 20, n // 2), np.exp(rng.uniform(-30, 30, n // 4)), rng.uniform(-1, 1, n // 4)]).astype(np.float32)
+    y = np.concatenate([rng.uniform(-4, 4, n // 2), rng.uniform(-2, 2, n // 2)]).astype(np.float32)
+    x[:8] = [0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 1e-45]
+    r = ptamd.Renderer()
+    dev = r.detmath_probe(x, y)
+    host = orc.detmath_probe(x, y)
+    names = ['sinf', 'cosf', 'expf', 'logf', 'log2f', 'powf', 'acosf', 'atan2f', 'rcp', 'sqrtf', 'div', 'pow(double)']
+    for k, nme in enumerate(names):
+        a, b = bits(dev[:, k]), bits(host[:, k])
+        same = (a == b) | (np.isnan(dev[:, k]) & np.isnan(host[:, k]))
+        assert same.all(), '%s differs on %d of %d inputs, first x=%r y=%r' % (nme, (~same).sum(), n, x[~same][0], y[~same][0])
+    r.close()
+
+
+@pytest.mark.parametrize('n_tri', [1, 5, 300, 20000])
+def test_closest_hit_bit_exact_vs_brute_force(n_tri):
+    extent = {1: 50.0, 5: 50.0, 300: 60.0, 20000: 250.0}[n_tri]
+    b = util.soup(n_tri, seed=10 + n_tri, extent=extent, edge=8.0)
+    rays = scenes.random_rays(20000, seed=3, extent=extent * 1.1)
+    if n_tri <= 5:      # aim at the few triangles so that some rays hit
+        c = b.tris['a'][np.arange(len(rays)) % n_tri] + 0.3 * (b.tris['b'] - b.tris['a'])[np.arange(len(rays)) % n_tri]
+        d = c - rays['o']
+        rays['d'] = d / np.linalg.norm(d, axis=1, keepdims=True)
+    P = ptamd.default_params(64, 64)
+    r = b.renderer(P)
+    got = r.trace_closest(rays)
+    want = orc.closest_brute(b.oracle(), rays)
+    assert np.array_equal(got['tri'], want['tri'])
+    assert np.array_equal(bits(got['t']), bits(want['t']))
+    assert (got['tri'] != 0xFFFFFFFF).sum() > 0
+    r.close()
+
+
+def test_closest_hit_and_counters_vs_oracle_traversal_atrium():
+    b = util.atrium(detail=0.35)
+    P = scenes.atrium_params(ptamd.default_params(64, 64))
+    rays = scenes.random_rays(200000, seed=5, extent=1400.0)
+    rays['o'][:, 1] = np.abs(rays['o'][:, 1]) * 0.8
+    r = b.renderer(P)
+    got, nb, nt = r.trace_closest(rays, counted=True)
+    want, wb, wt = orc.closest_bvh(b.oracle(), rays, counted=True)
+    assert np.array_equal(got['tri'], want['tri'])
+    assert np.array_equal(bits(got['t']), bits(want['t']))
+    assert np.array_equal(nb, wb) and np.array_equal(nt, wt)
+    # a sample against exhaustive search
+    sub = rays[:2000]
+    brute = orc.closest_brute(b.oracle(), sub)
+    assert np.array_equal(got['tri'][:2000], brute['tri']) and np.array_equal(bits(got['t'][:2000]), bits(brute['t']))
+    r.close()
+
+
+def test_non_finite_rays_miss():
+    b = util.soup(300, seed=310, extent=60.0, edge=8.0)
+    rays = scenes.random_rays(64, seed=1, extent=60.0)
+    rays['d'][0] = [np.nan, 0, 1]
+    rays['o'][1] = [np.inf, 0, 0]
+    rays['d'][2] = [0, 0, 0]
+    r = b.renderer(ptamd.default_params(64, 64))
+    got = r.trace_closest(rays)
+    want = orc.closest_brute(b.oracle(), rays)
+    assert got['tri'][0] == 0xFFFFFFFF and got['tri'][1] == 0xFFFFFFFF
+    assert np.array_equal(got['tri'], want['tri']) and np.array_equal(bits(got['t']), bits(want['t']))
+    r.close()
+
+
+def _render_both(b, P, f0, f1, bounces):
+    r = b.renderer(P)
+    r.set_max_bounces(bounces)
+    r.enable_counters(True)
+    r.render(P, f0, f1)
+    acc = r.read_accum()
+    ctr = r.counters()
+    img = r.resolve_display(f1 - f0)
+    r.close()
+    want, st = orc.render(b.oracle(P), P, f0, f1, bounces)
+    return acc, ctr, img, want, st
+
+
+def _assert_radiance(acc, want):
+    same = bits(acc) == bits(want)
+    if not same.all():
+        bad = (~same).sum()
+        raise AssertionError('%d of %d accumulator words differ; worst relative error %g' % (bad, same.size, rel_err(acc, want)))
+
+
+def test_cornell_radiance_matches_oracle():
+    b = util.cornell('black')
+    P = scenes.cornell_params(ptamd.default_params(64, 64))
+    acc, ctr, img, want, st = _render_both(b, P, 0, 8, 4)
+    _assert_radiance(acc, want)
+    for k in ('rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps'):
+        assert ctr[k] == st[k], k
+    assert np.array_equal(img, orc.resolve_display(want, 8))
+    assert want.sum() > 0
+
+
+def test_cornell_with_sky_light_long_paths():
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(48, 48))
+    acc, ctr, img, want, st = _render_both(b, P, 3, 7, 512)
+    _assert_radiance(acc, want)
+    assert ctr['rays'] == st['rays']
+    assert np.array_equal(img, orc.resolve_display(want, 4))
+
+
+def test_atrium_radiance_matches_oracle():
+    b = util.atrium(detail=0.35, env_size=(256, 128))
+    P = scenes.atrium_params(ptamd.default_params(96, 56))
+    acc, ctr, img, want, st = _render_both(b, P, 0, 2, 512)
+    _assert_radiance(acc, want)
+    for k in ('rays', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps'):
+        assert ctr[k] == st[k], k
+    assert np.array_equal(img, orc.resolve_display(want, 2))
+
+
+def test_thin_lens_and_preview_modes():
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(40, 40))
+    P.DOF_strenght = 4.0
+    P.focalDistance = 300.0
+    acc, _, _, want, _ = _render_both(b, P, 0, 3, 6)
+    _assert_radiance(acc, want)
+    P.DOF_strenght = 0.0
+    P.isRendering = 0
+    acc, _, _, want, _ = _render_both(b, P, 0, 1, 6)
+    _assert_radiance(acc, want)
+
+
+def test_sun_sky_mode_glossy_dielectric():
+    b = util.atrium(detail=0.3, env_size=(64, 32), glossy=0.3, glass=0.2, sky_mode=1)
+    P = scenes.atrium_params(ptamd.default_params(64, 40))
+    acc, ctr, img, want, st = _render_both(b, P, 0, 2, 16)
+    _assert_radiance(acc, want)
+    assert ctr['env_samples'] == 0 and st['env_samples'] == 0
+    assert ctr['rays'] == st['rays']
+
+
+def test_render_frame_matches_reference_frame_loop():
+    """pt_render_frame == render(): 1 spp per call, frame 0 overwrites, RGBA8 of accum/(frame+1)."""
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(32, 32))
+    r = b.renderer(P)
+    r.set_max_bounces(5)
+    S = b.oracle(P)
+    acc = np.zeros((32, 32, 3), np.float32)
+    for f in range(3):
+        P.frameIndex = f
+        img = r.render_frame(P)
+        acc, _ = orc.render(S, P, f, f + 1, 5, accum=acc)
+        assert np.array_equal(img, orc.resolve_display(acc, f + 1)), 'frame %d' % f
+    P.frameIndex = 0        # a camera move resets the accumulation (main.cpp:45)
+    img = r.render_frame(P)
+    acc0, _ = orc.render(S, P, 0, 1, 5)
+    assert np.array_equal(img, orc.resolve_display(acc0, 1))
+    r.close()
+
+
+def test_frame_ranges_compose():
+    """Frames [0,2) then [2,5) give the same accumulator as [0,5)."""
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(32, 32))
+    r = b.renderer(P)
+    r.set_max_bounces(4)
+    r.render(P, 0, 5)
+    whole = r.read_accum()
+    r.clear_accum()
+    r.render(P, 0, 2)
+    r.render(P, 2, 5)
+    parts = r.read_accum()
+    assert np.array_equal(bits(whole), bits(parts))
+    r.close()
