@@ -30,7 +30,8 @@ struct pt_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int W = 0, H = 0;
-    float* accum = nullptr;         // 3*W*H
+    float* accum = nullptr;         // 3*W*H, the buffer rendered into
+    float* own_accum = nullptr;     // allocated by pt_init
     uint8_t* display = nullptr;     // 4*W*H
     // scene, host copies
     std::vector<pt_triangle> tris;
@@ -104,7 +105,7 @@ void pt_destroy(pt_ctx* c)
     for (float* p : c->tex_data) (void)hipFree(p);
     if (c->d_env) (void)hipFree(c->d_env);
     if (c->d_cdf) (void)hipFree(c->d_cdf);
-    if (c->accum) (void)hipFree(c->accum);
+    if (c->own_accum) (void)hipFree(c->own_accum);
     if (c->display) (void)hipFree(c->display);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -126,9 +127,10 @@ int pt_init(pt_ctx* c, const pt_params* p)
     int W = p->windowSize.x, H = p->windowSize.y;
     if (W <= 0 || H <= 0 || (int64_t)W * H > (1 << 28)) { set_error("pt_init: bad window size %dx%d", W, H); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
-    if (c->accum) { (void)hipFree(c->accum); c->accum = nullptr; }
+    if (c->own_accum) { (void)hipFree(c->own_accum); c->own_accum = nullptr; c->accum = nullptr; }
     if (c->display) { (void)hipFree(c->display); c->display = nullptr; }
-    HIP_TRY(hipMalloc((void**)&c->accum, (size_t)W * H * 3 * sizeof(float)));
+    HIP_TRY(hipMalloc((void**)&c->own_accum, (size_t)W * H * 3 * sizeof(float)));
+    c->accum = c->own_accum;
     HIP_TRY(hipMalloc((void**)&c->display, (size_t)W * H * 4));
     HIP_TRY(hipMemsetAsync(c->accum, 0, (size_t)W * H * 3 * sizeof(float), c->stream));
     HIP_TRY(hipMemsetAsync(c->display, 0, (size_t)W * H * 4, c->stream));
@@ -418,7 +420,7 @@ static int fetch_counters(pt_ctx* c)
     HIP_TRY(hipMemcpyAsync(&h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->totals.rays += h.rays; c->totals.samples += h.samples; c->totals.box_tests += h.box_tests; c->totals.tri_tests += h.tri_tests;
-    c->totals.shade_vertices += h.shade_vertices; c->totals.env_samples += h.env_samples; c->totals.tex_taps += h.tex_taps;
+    c->totals.shade_vertices += h.shade_vertices; c->totals.env_samples += h.env_samples; c->totals.tex_taps += h.tex_taps; c->totals.tex_taps_r += h.tex_taps_r;
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(DCounters), c->stream));
     return PT_OK;
 }
@@ -485,6 +487,13 @@ int pt_accum_device_ptr(pt_ctx* c, float** out)
 {
     if (!c || !out || !c->accum) { set_error("pt_accum_device_ptr: bad argument"); return PT_ERR_ARG; }
     *out = c->accum;
+    return PT_OK;
+}
+
+int pt_bind_accum(pt_ctx* c, float* accum_dev)
+{
+    if (!c || !c->own_accum) { set_error("pt_bind_accum: call pt_init first"); return PT_ERR_STATE; }
+    c->accum = accum_dev ? accum_dev : c->own_accum;
     return PT_OK;
 }
 

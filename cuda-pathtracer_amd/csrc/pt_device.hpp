@@ -292,7 +292,7 @@ PT_DEV void default_mat(Mat& m)          // structs.cuh:75-94
 // pathtracer.cu:140-181: what triangleIntersect does after accepting a hit, evaluated once for the
 // final hit of a query (intermediate accepted hits never reach the caller).
 template <bool COUNT>
-PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& taps)
+PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& taps, uint32_t& taps_r)
 {
     s.t = h.t; s.hit = h.tri != PT_NO_TRI; s.inside = false; s.n = f3(0, 0, 0);
     default_mat(s.m);
@@ -329,9 +329,9 @@ PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& 
         s.m.alpha = r.w;
         if (COUNT) taps++;
     }
-    if (tx_r) { const DTex tx = S.tex[tx_r - 1]; s.m.rough = tex1(tx.texels, tx.w, tx.h, px, py); if (COUNT) taps++; }
-    if (tx_m) { const DTex tx = S.tex[tx_m - 1]; s.m.metal = tex1(tx.texels, tx.w, tx.h, px, py); if (COUNT) taps++; }
-    if (tx_e) { const DTex tx = S.tex[tx_e - 1]; float r = tex1(tx.texels, tx.w, tx.h, px, py); s.m.emis = f3(r, r, r); if (COUNT) taps++; }
+    if (tx_r) { const DTex tx = S.tex[tx_r - 1]; s.m.rough = tex1(tx.texels, tx.w, tx.h, px, py); if (COUNT) taps_r++; }
+    if (tx_m) { const DTex tx = S.tex[tx_m - 1]; s.m.metal = tex1(tx.texels, tx.w, tx.h, px, py); if (COUNT) taps_r++; }
+    if (tx_e) { const DTex tx = S.tex[tx_e - 1]; float r = tex1(tx.texels, tx.w, tx.h, px, py); s.m.emis = f3(r, r, r); if (COUNT) taps_r++; }
     if (tx_n) {
         F3 Tn, Bn;
         onb(s.n, Tn, Bn);
@@ -627,13 +627,13 @@ PT_DEV float4 eval_envmap(const DScene& S, F3 dir)
     return make_float4(r.x, r.y, r.z, (pdf * S.env_w * S.env_h) / (PT_TWO_PI * PT_PI * pt_sinf(theta)));
 }
 template <bool COUNT>
-PT_DEV F2 env_search(const DScene& S, float xi, uint32_t& taps)
+PT_DEV F2 env_search(const DScene& S, float xi, uint32_t& taps_r)
 {
     int lower = 0, upper = S.env_h - 1;
     while (lower < upper) {
         int mid = (lower + upper) >> 1;
         float c = tex1(S.env_cdf, S.env_w, S.env_h, 1.f, (float)mid / (float)S.env_h);
-        if (COUNT) taps++;
+        if (COUNT) taps_r++;
         if (xi < c) upper = mid; else lower = mid + 1;
     }
     int y = (int)clamp_((float)lower, 0.f, (float)(S.env_h - 1));
@@ -641,7 +641,7 @@ PT_DEV F2 env_search(const DScene& S, float xi, uint32_t& taps)
     while (lower < upper) {
         int mid = (lower + upper) >> 1;
         float c = tex1(S.env_cdf, S.env_w, S.env_h, (float)mid / (float)S.env_w, (float)y / (float)S.env_h);
-        if (COUNT) taps++;
+        if (COUNT) taps_r++;
         if (xi < c) upper = mid; else lower = mid + 1;
     }
     int x = (int)clamp_((float)lower, 0.f, (float)(S.env_w - 1));
@@ -650,9 +650,9 @@ PT_DEV F2 env_search(const DScene& S, float xi, uint32_t& taps)
 }
 // returns direction + pdf; color receives the radiance
 template <bool COUNT>
-PT_DEV float4 sample_envmap(const DScene& S, F3& color, Rng& rng, uint32_t& taps)
+PT_DEV float4 sample_envmap(const DScene& S, F3& color, Rng& rng, uint32_t& taps, uint32_t& taps_r)
 {
-    F2 uv = env_search<COUNT>(S, rng_next(rng) * S.env_sum, taps);
+    F2 uv = env_search<COUNT>(S, rng_next(rng) * S.env_sum, taps_r);
     float4 r = tex4(S.env_rgba, S.env_w, S.env_h, uv.x, uv.y);
     if (COUNT) taps++;
     color = f3(r.x, r.y, r.z);

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera ca
     if (x >= cam.W || y >= cam.H) return;
     size_t pix = (size_t)(x + y * cam.W) * 3;
     F3 acc = f3(accum[pix], accum[pix + 1], accum[pix + 2]);
-    Tally tl = {0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
     for (int frame = frame_begin; frame < frame_end; frame++) {
         Path P;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera ca
             Hit h = closest_hit<64, COUNT>(S, P.o, P.d, stack, threadIdx.x, tl.box, tl.tri);
             if (COUNT) tl.rays++;
             Surf info;
-            resolve_hit<COUNT>(S, h, P.d, info, tl.taps);
+            resolve_hit<COUNT>(S, h, P.d, info, tl.taps, tl.taps_r);
             if (info.hit) {
                 float NoV = pt_fmaxf(dot(P.d * -1.0f, info.n), 0.f);
                 color = NoV * info.m.base;
@@ -72,6 +72,7 @@ __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera ca
                 color = sky_gradient(P.d, ld3(S.sun));
             } else {
                 float4 e = eval_envmap(S, P.d);
+                if (COUNT) tl.taps++;
                 color = f3(e.x, e.y, e.z);
             }
         } else {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera ca
                 Hit h = closest_hit<64, COUNT>(S, ro, rd, stack, threadIdx.x, tl.box, tl.tri);
                 if (COUNT) tl.rays++;
                 Surf info;
-                resolve_hit<COUNT>(S, h, rd, info, tl.taps);
+                resolve_hit<COUNT>(S, h, rd, info, tl.taps, tl.taps_r);
                 if (shadow) on_shadow_hit<COUNT>(S, cam, P, info, tl);
                 else on_path_hit<COUNT>(S, cam, P, info, tl);
             }
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera ca
         atomicAdd(&ctr->shade_vertices, (unsigned long long)tl.verts);
         atomicAdd(&ctr->env_samples, (unsigned long long)tl.envs);
         atomicAdd(&ctr->tex_taps, (unsigned long long)tl.taps);
+        atomicAdd(&ctr->tex_taps_r, (unsigned long long)tl.taps_r);
     }
 }
 

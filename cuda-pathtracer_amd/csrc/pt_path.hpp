@@ -43,7 +43,7 @@ struct Path {
     bool v_inside;
 };
 
-struct Tally { uint32_t rays, box, tri, verts, envs, taps; };
+struct Tally { uint32_t rays, box, tri, verts, envs, taps, taps_r; };
 
 // pathtracer.cu:559-579 + 527: pixel seed, jitter, camera ray, optional thin lens, channel pick.
 PT_DEV void begin_sample(Path& P, const DCamera& cam, int x, int y, int frame)
@@ -153,7 +153,7 @@ PT_DEV void start_light(const DScene& S, const DCamera& cam, Path& P, F3 origin,
         return;
     }
     P.nee_skip = false;
-    float4 dat = sample_envmap<COUNT>(S, P.env_color, P.rng, tl.taps);
+    float4 dat = sample_envmap<COUNT>(S, P.env_color, P.rng, tl.taps, tl.taps_r);
     if (COUNT) tl.envs++;
     P.sd = f3(dat.x, dat.y, dat.z);
     P.env_pdf = dat.w;

@@ -19,7 +19,7 @@ EXPORTS = [
     'pt_last_error', 'pt_create', 'pt_destroy', 'pt_set_stream', 'pt_init', 'pt_clear_accum', 'pt_upload_triangles',
     'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_upload_texture', 'pt_upload_envmap',
     'pt_set_sky_mode', 'pt_set_max_bounces', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
-    'pt_accum_device_ptr', 'pt_resolve_display', 'pt_save_png', 'pt_trace_closest', 'pt_trace_closest_dev',
+    'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_trace_closest', 'pt_trace_closest_dev',
     'pt_trace_closest_counted', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_scene_bytes',
     'pt_detmath_probe', 'pt_read_obj', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
     'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
@@ -227,6 +227,9 @@ class Renderer:
         p = C.c_void_p()
         check(lib().pt_accum_device_ptr(self.h, C.byref(p)))
         return p.value
+
+    def bind_accum(self, ptr):
+        check(lib().pt_bind_accum(self.h, C.c_void_p(ptr)))
 
     def resolve_display(self, n_frames):
         W, H = self.params.windowSize.x, self.params.windowSize.y

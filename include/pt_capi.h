@@ -125,7 +125,8 @@ typedef struct pt_counters {
     uint64_t tri_tests;     /* ray/triangle tests */
     uint64_t shade_vertices;/* surface or medium events shaded */
     uint64_t env_samples;   /* envmap importance samples drawn */
-    uint64_t tex_taps;      /* bilinear texture lookups */
+    uint64_t tex_taps;      /* bilinear lookups into 4-channel textures (materials, environment radiance) */
+    uint64_t tex_taps_r;    /* bilinear lookups into 1-channel textures (roughness/metallic/emissive maps, environment CDF) */
     double   last_ms;       /* device time of the last render / trace call (HIP events) */
 } pt_counters;
 
@@ -154,6 +155,10 @@ int pt_set_max_bounces(pt_ctx* ctx, int max_bounces);                   /* patht
 int pt_render_headless(pt_ctx* ctx, const pt_params* params, int frame_begin, int frame_end); /* frames [begin,end): accum as pathtracer.cu:583-586, first frame overwrites */
 int pt_read_accum(pt_ctx* ctx, float* rgb_out);                         /* 3*W*H floats */
 int pt_accum_device_ptr(pt_ctx* ctx, float** accum_dev_out);            /* device address of the fp32 accumulator (for collectives) */
+int pt_bind_accum(pt_ctx* ctx, float* accum_dev);                       /* render into a caller-owned device buffer of 3*W*H floats (NULL = the context's own) */
+int pt_clear_accum(pt_ctx* ctx);                                        /* zero the accumulator (what frame 0 does at pathtracer.cu:583-584) */
+int pt_write_accum(pt_ctx* ctx, const float* rgb);                      /* restore an accumulator saved with pt_read_accum */
+int pt_sync(pt_ctx* ctx);                                               /* wait for the context's stream; updates last_ms */
 int pt_resolve_display(pt_ctx* ctx, int n_frames, uint8_t* rgba_out);   /* accum/n -> AgX -> RGBA8 (pathtracer.cu:588-599); rgba_out may be NULL */
 int pt_save_png(const char* path, const uint8_t* rgba, int w, int h);   /* saveToFile, main.cpp:96-114 */
 
@@ -163,7 +168,10 @@ int pt_trace_closest_dev(pt_ctx* ctx, const pt_ray* rays_dev, int n, pt_hit* hit
 int pt_trace_closest_counted(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hits_out, uint32_t* box_tests_out, uint32_t* tri_tests_out);
 
 int pt_get_counters(pt_ctx* ctx, pt_counters* out);
+int pt_reset_counters(pt_ctx* ctx);
 int pt_enable_counters(pt_ctx* ctx, int on);                            /* instrumented kernels (slower); off by default */
+int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* tri_bytes); /* size of the flattened BVH in HBM */
+int pt_detmath_probe(pt_ctx* ctx, const float* x, const float* y, int n, float* out12); /* device evaluation of include/pt_detmath.h, 12 results per input pair */
 
 /* ---- host-side producers (no GPU needed) ---- */
 typedef struct pt_host_scene pt_host_scene;

@@ -172,11 +172,11 @@ struct Rng {
 // ---------------------------------------------------------------- scene view
 struct OrcTexture { const float* texels; int w, h, comps; };
 struct Stats {
-    uint64_t rays = 0, samples = 0, box_tests = 0, tri_tests = 0, shade_vertices = 0, env_samples = 0, tex_taps = 0;
+    uint64_t rays = 0, samples = 0, box_tests = 0, tri_tests = 0, shade_vertices = 0, env_samples = 0, tex_taps = 0, tex_taps_r = 0;
     void add(const Stats& o)
     {
         rays += o.rays; samples += o.samples; box_tests += o.box_tests; tri_tests += o.tri_tests;
-        shade_vertices += o.shade_vertices; env_samples += o.env_samples; tex_taps += o.tex_taps;
+        shade_vertices += o.shade_vertices; env_samples += o.env_samples; tex_taps += o.tex_taps; tex_taps_r += o.tex_taps_r;
     }
 };
 struct Scene {
@@ -227,7 +227,7 @@ inline void tex_fetch(const OrcTexture& T, float u, float v, float out[4], Stats
     float bx = 1.0f - ax, by = 1.0f - ay;
     for (int c = 0; c < T.comps; c++)
         out[c] = (p00[c] * bx + p10[c] * ax) * by + (p01[c] * bx + p11[c] * ax) * ay;
-    if (st) st->tex_taps++;
+    if (st) { if (T.comps == 4) st->tex_taps++; else st->tex_taps_r++; }
 }
 
 // ---------------------------------------------------------------- intersection
@@ -1083,7 +1083,7 @@ struct orc_scene {
     int sky_mode;
     float sun[3];
 };
-struct orc_stats { uint64_t rays, samples, box_tests, tri_tests, shade_vertices, env_samples, tex_taps; };
+struct orc_stats { uint64_t rays, samples, box_tests, tri_tests, shade_vertices, env_samples, tex_taps, tex_taps_r; };
 struct orc_hit { float t; uint32_t tri; float u, v; };
 
 } // extern "C"
@@ -1102,7 +1102,7 @@ void put(orc_stats* o, const Stats& s)
 {
     if (!o) return;
     o->rays = s.rays; o->samples = s.samples; o->box_tests = s.box_tests; o->tri_tests = s.tri_tests;
-    o->shade_vertices = s.shade_vertices; o->env_samples = s.env_samples; o->tex_taps = s.tex_taps;
+    o->shade_vertices = s.shade_vertices; o->env_samples = s.env_samples; o->tex_taps = s.tex_taps; o->tex_taps_r = s.tex_taps_r;
 }
 }
 

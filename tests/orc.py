@@ -23,7 +23,7 @@ class OrcScene(C.Structure):
 
 class OrcStats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in ('rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices',
-                                          'env_samples', 'tex_taps')]
+                                          'env_samples', 'tex_taps', 'tex_taps_r')]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

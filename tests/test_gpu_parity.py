@@ -111,7 +111,7 @@ def test_cornell_radiance_matches_oracle():
     P = scenes.cornell_params(ptamd.default_params(64, 64))
     acc, ctr, img, want, st = _render_both(b, P, 0, 8, 4)
     _assert_radiance(acc, want)
-    for k in ('rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps'):
+    for k in ('rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps', 'tex_taps_r'):
         assert ctr[k] == st[k], k
     assert np.array_equal(img, orc.resolve_display(want, 8))
     assert want.sum() > 0
@@ -131,8 +131,9 @@ def test_atrium_radiance_matches_oracle():
     P = scenes.atrium_params(ptamd.default_params(96, 56))
     acc, ctr, img, want, st = _render_both(b, P, 0, 2, 512)
     _assert_radiance(acc, want)
-    for k in ('rays', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps'):
-        assert ctr[k] == st[k], k
+    for k in ('rays', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps', 'tex_taps_r'):
+        assert ctr[k] == st[k] and st[k] > 0, k
+    assert st['rays'] > 3 * st['samples'] and want.sum() > 0
     assert np.array_equal(img, orc.resolve_display(want, 2))
 
 
