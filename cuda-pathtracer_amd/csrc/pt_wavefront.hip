@@ -1,0 +1,392 @@
+// Wavefront form of the render path: the per-sample state machine of pt_path.hpp cut into stage
+// kernels over a pool of path slots that live in HBM.
+//
+//   generate : every slot takes a sample id and builds its camera ray
+//   extend   : closest hit for the pending ray of every live slot (camera, bounce and shadow-walk
+//              rays alike); small register footprint, traversal stack in LDS, high occupancy
+//   shade    : consumes the hit (material resolve, medium/surface event, light-sample set-up, shadow
+//              segment bookkeeping); slots whose vertex is ready to pick its next direction are
+//              appended to the bsdf queue with a wave-aggregated atomic
+//   bsdf     : Disney evaluation for the light sample, direction sampling, roulette (the fat,
+//              divergent code), run only over the compacted queue
+//   accumulate: adds the per-sample results to the accumulator in frame order per pixel
+//
+// A slot whose sample is finished writes the sample's value to a staging array and immediately
+// takes the next unstarted sample id from a global counter (wave-aggregated), so the pool stays
+// full until the work runs out.  Which slot renders which sample does not matter: a sample's value
+// depends only on (pixel, frame) through its counter-based random stream, and the ordered
+// accumulate pass makes the sum independent of scheduling.  Results are therefore bit-identical to
+// the frame loop of the reference (pathtracer.cu:583-586) whatever the pool size.
+#include <hip/hip_runtime.h>
+#include "pt_path.hpp"
+#include "pt_launch.h"
+
+#pragma clang fp contract(off)
+
+namespace ptamd {
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// flags word: state[1:0] ch[3:2] inside[4] surface_scatter[5] sh_inside[6] nee_surface[7] nee_skip[8] v_inside[9] seg[15:10]
+PT_DEV uint32_t pack_flags(const Path& P)
+{
+    return (uint32_t)P.state | ((uint32_t)(P.ch & 3) << 2) | ((uint32_t)P.inside << 4) | ((uint32_t)P.surface_scatter << 5) |
+           ((uint32_t)P.sh_inside << 6) | ((uint32_t)P.nee_surface << 7) | ((uint32_t)P.nee_skip << 8) | ((uint32_t)P.v_inside << 9) |
+           ((uint32_t)(P.seg & 63) << 10);
+}
+PT_DEV void unpack_flags(Path& P, uint32_t f)
+{
+    P.state = (int)(f & 3u); P.ch = (int)((f >> 2) & 3u); P.inside = (f >> 4) & 1u; P.surface_scatter = (f >> 5) & 1u;
+    P.sh_inside = (f >> 6) & 1u; P.nee_surface = (f >> 7) & 1u; P.nee_skip = (f >> 8) & 1u; P.v_inside = (f >> 9) & 1u;
+    P.seg = (int)((f >> 10) & 63u);
+}
+
+struct SampleId { int x, y, frame; uint32_t pixel; uint32_t stage_index; };
+
+// sample id -> (pixel, frame). Pixels are walked in 8x8 tiles when the image allows it, so that the
+// 64 samples a wave takes together form one tile (coherent camera rays), else row by row.
+PT_DEV SampleId decode_sample(const WfParams& w, uint32_t s)
+{
+    SampleId id;
+    uint32_t npix = (uint32_t)(w.W * w.H);
+    uint32_t fr = s / npix, p = s - fr * npix;
+    if (w.tiled) {
+        uint32_t tiles_x = (uint32_t)w.W >> 3;
+        uint32_t tile = p >> 6, l = p & 63u;
+        id.x = (int)((tile % tiles_x) * 8 + (l & 7u));
+        id.y = (int)((tile / tiles_x) * 8 + (l >> 3));
+    } else {
+        id.x = (int)(p % (uint32_t)w.W);
+        id.y = (int)(p / (uint32_t)w.W);
+    }
+    id.frame = w.frame_begin + (int)fr;
+    id.pixel = (uint32_t)(id.x + id.y * w.W);
+    id.stage_index = fr * npix + id.pixel;
+    return id;
+}
+
+// ---- slot state in HBM: structure of 16-byte arrays, slot-indexed, so a wave's access is contiguous
+PT_DEV void store_ray(const WfParams& w, uint32_t slot, const Path& P)
+{
+    bool shadow = P.state == ST_SHADOW;
+    F3 o = shadow ? P.so : P.o, d = shadow ? P.sd : P.d;
+    int live = (P.state == ST_PATH || P.state == ST_SHADOW) ? 1 : 0;
+    w.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.f);
+    w.ray_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float(live));
+}
+PT_DEV void store_core(const WfParams& w, uint32_t slot, const Path& P, uint32_t sample)
+{
+    w.c0[slot] = make_float4(P.o.x, P.o.y, P.o.z, P.thr);
+    w.c1[slot] = make_float4(P.d.x, P.d.y, P.d.z, P.pdf);
+    w.c2[slot] = make_float4(P.result, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), __uint_as_float(sample));
+}
+PT_DEV uint32_t load_core(const WfParams& w, uint32_t slot, Path& P, SampleId& id)
+{
+    float4 a = w.c0[slot], b = w.c1[slot], c = w.c2[slot];
+    P.o = f3(a.x, a.y, a.z); P.thr = a.w;
+    P.d = f3(b.x, b.y, b.z); P.pdf = b.w;
+    P.result = c.x;
+    unpack_flags(P, __float_as_uint(c.y));
+    uint32_t sample = __float_as_uint(c.w);
+    id = decode_sample(w, sample);
+    rng_seed(P.rng, id.pixel, (uint32_t)id.frame, __float_as_uint(c.z));
+    return sample;
+}
+PT_DEV void store_light(const WfParams& w, uint32_t slot, const Path& P)
+{
+    w.d0[slot] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
+    w.d1[slot] = make_float4(P.env_color.x, P.env_color.y, P.env_color.z, __int_as_float(P.bounce));
+}
+PT_DEV void load_light(const WfParams& w, uint32_t slot, Path& P)
+{
+    float4 a = w.d0[slot], b = w.d1[slot];
+    P.light = f3(a.x, a.y, a.z); P.env_pdf = a.w;
+    P.env_color = f3(b.x, b.y, b.z); P.bounce = __float_as_int(b.w);
+}
+PT_DEV void store_vertex(const WfParams& w, uint32_t slot, const Path& P)
+{
+    const Mat& m = P.vm;
+    w.e0[slot] = make_float4(m.base.x, m.base.y, m.base.z, m.rough);
+    w.e1[slot] = make_float4(m.emis.x, m.emis.y, m.emis.z, m.aniso);
+    w.e2[slot] = make_float4(m.metal, m.subsurf, m.sheen, m.coat);
+    w.e3[slot] = make_float4(m.coat_rough, m.strans, m.ior, m.G);
+    w.e4[slot] = make_float4(P.vn.x, P.vn.y, P.vn.z, m.alpha);
+}
+PT_DEV void load_vertex(const WfParams& w, uint32_t slot, Path& P)
+{
+    float4 a = w.e0[slot], b = w.e1[slot], c = w.e2[slot], d = w.e3[slot], e = w.e4[slot];
+    Mat& m = P.vm;
+    m.base = f3(a.x, a.y, a.z); m.rough = a.w;
+    m.emis = f3(b.x, b.y, b.z); m.aniso = b.w;
+    m.metal = c.x; m.subsurf = c.y; m.sheen = c.z; m.coat = c.w;
+    m.coat_rough = d.x; m.strans = d.y; m.ior = d.z; m.G = d.w;
+    P.vn = f3(e.x, e.y, e.z); m.alpha = e.w;
+    m.sigA = f3(0.f, 0.f, 0.f); m.sigS = f3(0.f, 0.f, 0.f);     // not used after the vertex
+}
+
+// Hands `need` lanes consecutive values from a global counter with one atomic per wave.
+PT_DEV uint32_t wave_take(uint32_t* counter, bool need)
+{
+    unsigned long long mask = __ballot(need);
+    uint32_t id = 0;
+    if (mask != 0ull) {
+        int lane = (int)(threadIdx.x & 63u);
+        int leader = __ffsll((long long)mask) - 1;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        id = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    }
+    return id;
+}
+
+// A finished sample: publish its value (pathtracer.cu:540,580: channel value * 3, clamped below at 0)
+// and start the next unstarted sample in this slot, if any.
+template <bool COUNT>
+PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_t slot, Path& P, uint32_t& sample, SampleId& id, bool finished, uint32_t& nsamples)
+{
+    // bounded: a fresh sample is only born finished when its channel draw is exactly 1.0
+    for (int round = 0; round < 4; round++) {
+        if (finished) {
+            float v = P.result * 3.f;
+            w.staging[id.stage_index] = v > 0.f ? v : 0.f;
+        }
+        uint32_t next = wave_take(w.counters + WF_CTR_NEXT_SAMPLE, finished);
+        if (!__any(finished)) break;
+        if (finished) {
+            if (next < w.n_samples) {
+                sample = next;
+                id = decode_sample(w, sample);
+                begin_sample(P, cam, id.x, id.y, id.frame);
+                if (COUNT) nsamples++;
+                finished = P.state == ST_DONE;
+            } else {
+                P.state = ST_DONE;      // pool slot retires
+                sample = 0xFFFFFFFFu;
+                finished = false;
+            }
+        }
+    }
+}
+
+template <bool COUNT>
+PT_DEV void flush_tally(DCounters* ctr, const Tally& tl, uint32_t nsamples)
+{
+    if (!COUNT) return;
+    // one atomic per counter per wave
+    auto wave_sum = [](uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_down((int)v, o, 64); return v; };
+    uint32_t r = wave_sum(tl.rays), b = wave_sum(tl.box), t = wave_sum(tl.tri), v = wave_sum(tl.verts), e = wave_sum(tl.envs);
+    uint32_t x = wave_sum(tl.taps), y = wave_sum(tl.taps_r), s = wave_sum(nsamples);
+    if ((threadIdx.x & 63u) == 0) {
+        if (r) atomicAdd(&ctr->rays, (unsigned long long)r);
+        if (b) atomicAdd(&ctr->box_tests, (unsigned long long)b);
+        if (t) atomicAdd(&ctr->tri_tests, (unsigned long long)t);
+        if (v) atomicAdd(&ctr->shade_vertices, (unsigned long long)v);
+        if (e) atomicAdd(&ctr->env_samples, (unsigned long long)e);
+        if (x) atomicAdd(&ctr->tex_taps, (unsigned long long)x);
+        if (y) atomicAdd(&ctr->tex_taps_r, (unsigned long long)y);
+        if (s) atomicAdd(&ctr->samples, (unsigned long long)s);
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------- generate
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera cam, DCounters* ctr)
+{
+    uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= (uint32_t)w.n_slots) return;       // n_slots is a multiple of 64: whole waves leave together
+    Path P;
+    P.state = ST_DONE; P.result = 0.f; P.ch = 0; P.rng.draws = 0;
+    P.inside = P.surface_scatter = P.sh_inside = P.nee_surface = P.nee_skip = P.v_inside = false;
+    P.seg = 0; P.bounce = 0; P.thr = 1.f; P.pdf = 0.f;
+    P.o = P.d = P.so = P.sd = P.light = P.env_color = f3(0.f, 0.f, 0.f); P.env_pdf = 0.f;
+    uint32_t sample = 0xFFFFFFFFu;
+    SampleId id = decode_sample(w, 0);
+    uint32_t nsamples = 0;
+    // first fill: pretend every slot just finished a sample it never had (nothing is published)
+    {
+        uint32_t next = wave_take(w.counters + WF_CTR_NEXT_SAMPLE, true);
+        bool finished = false;
+        if (next < w.n_samples) {
+            sample = next;
+            id = decode_sample(w, sample);
+            begin_sample(P, cam, id.x, id.y, id.frame);
+            if (COUNT) nsamples++;
+            finished = P.state == ST_DONE;
+        }
+        finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples);
+    }
+    store_ray(w, slot, P);
+    store_core(w, slot, P, sample);
+    store_light(w, slot, P);
+    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    flush_tally<COUNT>(ctr, tl, nsamples);
+}
+
+// ---------------------------------------------------------------- extend
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S, DCounters* ctr)
+{
+    __shared__ uint2 stack[kLdsDepth * kBlock];
+    uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= (uint32_t)w.n_slots) return;
+    float4 rd = w.ray_d[slot];
+    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    if (__float_as_int(rd.w) != 0) {
+        float4 ro = w.ray_o[slot];
+        Hit h = closest_hit<kBlock, COUNT>(S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), stack, threadIdx.x, tl.box, tl.tri);
+        if (COUNT) tl.rays++;
+        w.hit[slot] = make_float4(h.t, __uint_as_float(h.tri), h.u, h.v);
+    }
+    flush_tally<COUNT>(ctr, tl, 0);
+}
+
+// ---------------------------------------------------------------- shade
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_shade_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+{
+    uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= (uint32_t)w.n_slots) return;
+    float4 rd4 = w.ray_d[slot];
+    bool live = __float_as_int(rd4.w) != 0;
+    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t nsamples = 0;
+    Path P;
+    SampleId id;
+    uint32_t sample = 0xFFFFFFFFu;
+    bool finished = false;
+    if (live) {
+        sample = load_core(w, slot, P, id);
+        load_light(w, slot, P);
+        float4 ro4 = w.ray_o[slot];
+        float4 h4 = w.hit[slot];
+        Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
+        F3 rdir = f3(rd4.x, rd4.y, rd4.z);
+        Surf info;
+        resolve_hit<COUNT>(S, h, rdir, info, tl.taps, tl.taps_r);
+        if (P.state == ST_SHADOW) {
+            P.so = f3(ro4.x, ro4.y, ro4.z); P.sd = rdir;
+            on_shadow_hit<COUNT>(S, cam, P, info, tl);
+        } else {
+            on_path_hit<COUNT>(S, cam, P, info, tl);
+            if (P.state == ST_SHADOW || P.state == ST_AFTER) store_vertex(w, slot, P);
+        }
+        finished = P.state == ST_DONE;
+    }
+    // slots that reached the bsdf stage: append to the queue
+    bool to_bsdf = live && P.state == ST_AFTER;
+    uint32_t qpos = wave_take(w.counters + WF_CTR_BSDF_COUNT, to_bsdf);
+    if (to_bsdf) w.bsdf_queue[qpos] = slot;
+    if (__any(finished)) finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples);
+    if (live) {
+        if (P.state == ST_AFTER) {
+            // the bsdf stage reads the shadow direction from the ray arrays; mark the slot as having no ray to trace
+            w.ray_d[slot] = make_float4(P.sd.x, P.sd.y, P.sd.z, __int_as_float(0));
+        } else {
+            store_ray(w, slot, P);
+        }
+        store_core(w, slot, P, sample);
+        store_light(w, slot, P);
+    }
+    bool alive = live && (P.state != ST_DONE);
+    unsigned long long m = __ballot(alive);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(w.counters + WF_CTR_LIVE, (uint32_t)__popcll(m));
+    flush_tally<COUNT>(ctr, tl, nsamples);
+}
+
+// ---------------------------------------------------------------- bsdf
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_bsdf_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+{
+    uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t count = w.counters[WF_CTR_BSDF_COUNT];
+    if ((q & ~63u) >= count) return;            // whole wave beyond the queue
+    bool active = q < count;
+    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t nsamples = 0;
+    Path P;
+    SampleId id;
+    uint32_t sample = 0xFFFFFFFFu;
+    uint32_t slot = 0;
+    bool finished = false;
+    if (active) {
+        slot = w.bsdf_queue[q];
+        sample = load_core(w, slot, P, id);
+        load_light(w, slot, P);
+        load_vertex(w, slot, P);
+        float4 sd4 = w.ray_d[slot];
+        P.sd = f3(sd4.x, sd4.y, sd4.z);
+        after_light<COUNT>(S, cam, P, tl);
+        finished = P.state == ST_DONE;
+    }
+    if (__any(finished)) finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples);
+    if (active) {
+        store_ray(w, slot, P);
+        store_core(w, slot, P, sample);
+        store_light(w, slot, P);
+    }
+    flush_tally<COUNT>(ctr, tl, nsamples);
+}
+
+// ---------------------------------------------------------------- accumulate
+// pathtracer.cu:583-586 over the chunk: per pixel, frames in order; the channel a sample went to is
+// re-derived from its random stream (draw 2, or 4 with the thin lens: pathtracer.cu:562,577,527).
+__global__ __launch_bounds__(kBlock) void wf_accumulate_kernel(WfParams w, DCamera cam, float* __restrict__ accum)
+{
+    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
+    uint32_t npix = (uint32_t)(w.W * w.H);
+    if (p >= npix) return;
+    F3 acc = f3(accum[3 * (size_t)p], accum[3 * (size_t)p + 1], accum[3 * (size_t)p + 2]);
+    uint32_t ch_draw = cam.dof > 0.f ? 4u : 2u;
+    for (int f = 0; f < w.n_frames; f++) {
+        float v = w.staging[(size_t)f * npix + p];
+        Rng g;
+        rng_seed(g, p, (uint32_t)(w.frame_begin + f), ch_draw);
+        int ch = int(rng_next(g) * 3.);
+        F3 c0 = f3(ch == 0 ? v : 0.f, ch == 1 ? v : 0.f, ch == 2 ? v : 0.f);
+        acc = acc + c0;
+    }
+    accum[3 * (size_t)p] = acc.x; accum[3 * (size_t)p + 1] = acc.y; accum[3 * (size_t)p + 2] = acc.z;
+}
+
+// ---------------------------------------------------------------- launchers
+__global__ void wf_reset_iteration_kernel(uint32_t* counters)
+{
+    counters[WF_CTR_LIVE_PREV] = counters[WF_CTR_LIVE];
+    counters[WF_CTR_LIVE] = 0;
+    counters[WF_CTR_BSDF_COUNT] = 0;
+}
+
+void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, hipStream_t s)
+{
+    dim3 grid((w.n_slots + kBlock - 1) / kBlock), block(kBlock);
+    if (ctr) hipLaunchKernelGGL(wf_generate_kernel<true>, grid, block, 0, s, w, cam, ctr);
+    else hipLaunchKernelGGL(wf_generate_kernel<false>, grid, block, 0, s, w, cam, ctr);
+}
+
+void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s)
+{
+    dim3 grid((w.n_slots + kBlock - 1) / kBlock), block(kBlock);
+    hipLaunchKernelGGL(wf_reset_iteration_kernel, dim3(1), dim3(1), 0, s, w.counters);
+    if (ctr) {
+        hipLaunchKernelGGL(wf_extend_kernel<true>, grid, block, 0, s, w, S, ctr);
+        hipLaunchKernelGGL(wf_shade_kernel<true>, grid, block, 0, s, w, S, cam, ctr);
+        hipLaunchKernelGGL(wf_bsdf_kernel<true>, grid, block, 0, s, w, S, cam, ctr);
+    } else {
+        hipLaunchKernelGGL(wf_extend_kernel<false>, grid, block, 0, s, w, S, ctr);
+        hipLaunchKernelGGL(wf_shade_kernel<false>, grid, block, 0, s, w, S, cam, ctr);
+        hipLaunchKernelGGL(wf_bsdf_kernel<false>, grid, block, 0, s, w, S, cam, ctr);
+    }
+}
+
+void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, hipStream_t s)
+{
+    int npix = w.W * w.H;
+    hipLaunchKernelGGL(wf_accumulate_kernel, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, s, w, cam, accum_dev);
+}
+
+} // namespace ptamd
