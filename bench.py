@@ -47,6 +47,8 @@ def main():
     ap.add_argument('--detail', type=float, default=None, help='atrium tessellation (default: about 262k triangles)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU oracle baseline')
     ap.add_argument('--cpu-spp', type=int, default=1)
+    ap.add_argument('--mode', choices=['wavefront', 'single_kernel'], default='wavefront')
+    ap.add_argument('--pool', type=int, default=0, help='wavefront pool slots (0 = library default)')
     args = ap.parse_args()
 
     import torch
@@ -75,6 +77,9 @@ def main():
     P = scenes.atrium_params(ptamd.default_params(W, H))
     r = bundle.renderer(P, local_rank)
     r.set_max_bounces(args.bounces)
+    r.set_mode(0 if args.mode == 'wavefront' else 1)
+    if args.pool:
+        r.set_pool(args.pool, 64)
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device='cuda')
@@ -103,12 +108,14 @@ def main():
 
     for k in range(args.warmup):
         step(k, False)
+    r.stage_timing(True)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k, True)
     barrier()
     elapsed = time.perf_counter() - t0
+    extend_ms, extend_launches = r.stage_timing(False)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -133,8 +140,15 @@ def main():
     result = None
     if rank == 0:
         mrays = tot['rays'] / elapsed / 1e6
-        kms = float(np.mean(kernel_ms))
-        alg_per_launch = algorithmic_bytes(loc) / args.steps
+        if args.mode == 'wavefront':
+            # dominant kernel: extend (closest hit for every pending ray of the pool), one launch per iteration
+            kname = 'wf_extend_kernel'
+            kms = extend_ms / max(extend_launches, 1)
+            alg_per_launch = (40 * loc['rays'] + 32 * loc['box_tests'] + 48 * loc['tri_tests']) / max(extend_launches, 1)
+        else:
+            kname = 'render_samples_kernel'
+            kms = float(np.mean(kernel_ms))
+            alg_per_launch = algorithmic_bytes(loc) / args.steps
         achieved = alg_per_launch / (kms * 1e-3) / 1e9
         node_b, tri_b = r.scene_bytes()
         traffic = None
@@ -159,9 +173,9 @@ def main():
                                    % (len(bundle.tris), W, H, spp, args.bounces),
                        'partition': 'samples: rank r renders frames [(k*N+r)*spp, +spp), RCCL reduce to rank 0' if world > 1 else 'single GPU',
                        'scene_bytes': {'nodes': node_b, 'triangles': tri_b}},
-            'roofline': {'bound': 'hbm', 'kernel': 'render_samples_kernel', 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': kname, 'launches': int(extend_launches) if args.mode == 'wavefront' else args.steps, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
-                         'kernel_ms': round(kms, 3), 'algorithmic_bytes_per_launch': int(alg_per_launch)},
+                         'kernel_ms': round(kms, 4), 'whole_path_algorithmic_GBs': round(algorithmic_bytes(loc) / (elapsed * 1e9), 2), 'algorithmic_bytes_per_launch': int(alg_per_launch)},
         }
 
     # CPU baseline: the oracle on this host's cores, rank 0, single-GPU runs only, bounded sample

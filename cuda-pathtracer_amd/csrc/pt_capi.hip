@@ -53,6 +53,21 @@ struct pt_ctx {
     DCounters* d_ctr = nullptr;
     pt_counters totals{};
     size_t n_nodes = 0;
+    // wavefront pool
+    int mode = PT_MODE_WAVEFRONT;
+    int pool_slots = 1 << 21;
+    int chunk_frames = 64;
+    void* wf_block = nullptr;       // one allocation holding every slot array
+    size_t wf_block_bytes = 0;
+    float* wf_staging = nullptr;
+    size_t wf_staging_bytes = 0;
+    uint32_t* wf_counters = nullptr;
+    uint32_t* wf_host_counters = nullptr;   // pinned
+    uint64_t wf_iterations = 0;
+    bool stage_timing = false;
+    hipEvent_t st_ev[16] = {};
+    double extend_ms = 0.0;
+    uint64_t extend_launches = 0;
 };
 
 extern "C" {
@@ -103,11 +118,16 @@ void pt_destroy(pt_ctx* c)
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_tex) (void)hipFree(c->d_tex);
     for (float* p : c->tex_data) (void)hipFree(p);
+    for (hipEvent_t e : c->st_ev) if (e) (void)hipEventDestroy(e);
     if (c->d_env) (void)hipFree(c->d_env);
     if (c->d_cdf) (void)hipFree(c->d_cdf);
     if (c->own_accum) (void)hipFree(c->own_accum);
     if (c->display) (void)hipFree(c->display);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
+    if (c->wf_block) (void)hipFree(c->wf_block);
+    if (c->wf_staging) (void)hipFree(c->wf_staging);
+    if (c->wf_counters) (void)hipFree(c->wf_counters);
+    if (c->wf_host_counters) (void)hipHostFree(c->wf_host_counters);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -425,6 +445,105 @@ static int fetch_counters(pt_ctx* c)
     return PT_OK;
 }
 
+// Sizes the slot pool and the staging array for a render of `frames` frames.
+static int wf_prepare(pt_ctx* c, int frames, WfParams* w)
+{
+    size_t npix = (size_t)c->W * c->H;
+    size_t n_samples = npix * (size_t)frames;
+    size_t slots = n_samples < (size_t)c->pool_slots ? n_samples : (size_t)c->pool_slots;
+    slots = (slots + 255) / 256 * 256;
+    size_t per_slot = 13 * sizeof(float4) + sizeof(uint32_t);
+    size_t need = slots * per_slot;
+    if (need > c->wf_block_bytes) {
+        if (c->wf_block) { (void)hipFree(c->wf_block); c->wf_block = nullptr; c->wf_block_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->wf_block, need));
+        c->wf_block_bytes = need;
+    }
+    size_t sbytes = n_samples * sizeof(float);
+    if (sbytes > c->wf_staging_bytes) {
+        if (c->wf_staging) { (void)hipFree(c->wf_staging); c->wf_staging = nullptr; c->wf_staging_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&c->wf_staging, sbytes));
+        c->wf_staging_bytes = sbytes;
+    }
+    if (!c->wf_counters) {
+        HIP_TRY(hipMalloc((void**)&c->wf_counters, WF_CTR_WORDS * sizeof(uint32_t)));
+        HIP_TRY(hipHostMalloc((void**)&c->wf_host_counters, WF_CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    float4* base = (float4*)c->wf_block;
+    float4** arrays[13] = {&w->ray_o, &w->ray_d, &w->hit, &w->c0, &w->c1, &w->c2, &w->d0, &w->d1, &w->e0, &w->e1, &w->e2, &w->e3, &w->e4};
+    for (int i = 0; i < 13; i++) *arrays[i] = base + (size_t)i * slots;
+    w->bsdf_queue = (uint32_t*)(base + (size_t)13 * slots);
+    w->counters = c->wf_counters;
+    w->staging = c->wf_staging;
+    w->n_slots = (int)slots;
+    w->n_samples = (uint32_t)n_samples;
+    w->W = c->W; w->H = c->H;
+    w->tiled = (c->W % 8 == 0 && c->H % 8 == 0) ? 1 : 0;
+    w->n_frames = frames;
+    return PT_OK;
+}
+
+// Frames [f0, f1) through the stage kernels, in chunks that bound the staging memory.
+static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
+{
+    size_t npix = (size_t)c->W * c->H;
+    int max_chunk = c->chunk_frames;
+    while (max_chunk > 1 && npix * (size_t)max_chunk > ((size_t)1 << 30)) max_chunk /= 2;     // at most 2^30 samples (4 GiB of staging)
+    DCounters* ctr = c->counting ? c->d_ctr : nullptr;
+    for (int b = f0; b < f1; b += max_chunk) {
+        int frames = (f1 - b) < max_chunk ? (f1 - b) : max_chunk;
+        WfParams w{};
+        int rc = wf_prepare(c, frames, &w);
+        if (rc != PT_OK) return rc;
+        w.frame_begin = b;
+        HIP_TRY(hipMemsetAsync(c->wf_counters, 0, WF_CTR_WORDS * sizeof(uint32_t), c->stream));
+        launch_wf_generate(w, cam, ctr, c->stream);
+        HIP_TRY(hipGetLastError());
+        const int batch = 8;
+        if (c->stage_timing && !c->st_ev[0]) { for (int i = 0; i < 2 * batch; i++) HIP_TRY(hipEventCreate(&c->st_ev[i])); }
+        for (;;) {
+            for (int i = 0; i < batch; i++)
+                launch_wf_iteration(w, c->scene, cam, ctr, c->stream, c->stage_timing ? c->st_ev[2 * i] : nullptr, c->stage_timing ? c->st_ev[2 * i + 1] : nullptr);
+            HIP_TRY(hipGetLastError());
+            c->wf_iterations += batch;
+            HIP_TRY(hipMemcpyAsync(c->wf_host_counters, c->wf_counters, WF_CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->stage_timing) {
+                for (int i = 0; i < batch; i++) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->st_ev[2 * i], c->st_ev[2 * i + 1]) == hipSuccess) { c->extend_ms += ms; c->extend_launches++; } }
+            }
+            if (c->wf_host_counters[WF_CTR_LIVE] == 0) break;
+        }
+        launch_wf_accumulate(w, cam, c->accum, c->stream);
+        HIP_TRY(hipGetLastError());
+    }
+    return PT_OK;
+}
+
+int pt_stage_timing(pt_ctx* c, int on, double* extend_ms_out, uint64_t* extend_launches_out)
+{
+    if (!c) { set_error("null context"); return PT_ERR_ARG; }
+    if (extend_ms_out) *extend_ms_out = c->extend_ms;
+    if (extend_launches_out) *extend_launches_out = c->extend_launches;
+    c->stage_timing = on != 0;
+    c->extend_ms = 0.0; c->extend_launches = 0;
+    return PT_OK;
+}
+
+int pt_set_mode(pt_ctx* c, int mode)
+{
+    if (!c || (mode != PT_MODE_WAVEFRONT && mode != PT_MODE_SINGLE_KERNEL)) { set_error("pt_set_mode: bad argument"); return PT_ERR_ARG; }
+    c->mode = mode;
+    return PT_OK;
+}
+
+int pt_set_pool(pt_ctx* c, int slots, int chunk_frames)
+{
+    if (!c || slots < 64 || chunk_frames < 1) { set_error("pt_set_pool: bad argument"); return PT_ERR_ARG; }
+    c->pool_slots = slots;
+    c->chunk_frames = chunk_frames;
+    return PT_OK;
+}
+
 int pt_render_headless(pt_ctx* c, const pt_params* P, int frame_begin, int frame_end)
 {
     int rc = check_ready(c, true);
@@ -434,8 +553,12 @@ int pt_render_headless(pt_ctx* c, const pt_params* P, int frame_begin, int frame
     DCamera cam;
     if ((rc = make_camera(c, P, &cam)) != PT_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    launch_render_samples(c->scene, cam, frame_begin, frame_end, c->accum, c->counting ? c->d_ctr : nullptr, c->stream);
-    HIP_TRY(hipGetLastError());
+    if (c->mode == PT_MODE_WAVEFRONT && cam.is_rendering && frame_end > frame_begin) {
+        if ((rc = render_wavefront(c, cam, frame_begin, frame_end)) != PT_OK) return rc;
+    } else {
+        launch_render_samples(c->scene, cam, frame_begin, frame_end, c->accum, c->counting ? c->d_ctr : nullptr, c->stream);
+        HIP_TRY(hipGetLastError());
+    }
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     if (c->counting) { if ((rc = fetch_counters(c)) != PT_OK) return rc; }
     return PT_OK;

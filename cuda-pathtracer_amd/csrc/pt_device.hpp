@@ -191,52 +191,56 @@ PT_DEV bool tri_test(F3 a, F3 e1, F3 e2, F3 o, F3 d, float limit, float& t, floa
     return true;
 }
 
-// Per-lane traversal stack: the first kLdsDepth entries live in LDS ([entry][lane], so a wave's
-// access is one contiguous 512-byte row), deeper entries spill to private memory.
-constexpr int kLdsDepth = 16;
-constexpr int kSpillDepth = 48;
-struct StackEntry { int ref; float tn; };
-
-template <int BLOCK>
-struct TravStack {
-    uint2* lds;                 // &shared[0][tid]
-    uint2 spill[kSpillDepth];
-    int sp;
-    PT_DEV void init(uint2* shared_base, int tid) { lds = shared_base + tid; sp = 0; }
-    PT_DEV void push(int ref, float tn)
-    {
-        uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
-        if (sp < kLdsDepth) lds[sp * BLOCK] = e;
-        else if (sp - kLdsDepth < kSpillDepth) spill[sp - kLdsDepth] = e;
-        sp++;
-    }
-    PT_DEV StackEntry pop()
-    {
-        sp--;
-        uint2 e = sp < kLdsDepth ? lds[sp * BLOCK] : spill[(sp - kLdsDepth) < kSpillDepth ? (sp - kLdsDepth) : (kSpillDepth - 1)];
-        StackEntry r; r.ref = (int)e.x; r.tn = __uint_as_float(e.y);
-        return r;
-    }
-};
-
 // Closest hit (pathtracer.cu:185-266: BVHIntersect + map). Same visiting order as the reference:
 // the nearer child is entered first, the farther one is deferred together with its entry distance
 // and dropped on pop if that distance no longer beats the current hit. Exact-t ties go to the
 // lowest original triangle index. Rays with a non-finite component miss.
-template <int BLOCK, bool COUNT>
-PT_DEV Hit closest_hit(const DScene& S, F3 o, F3 d, uint2* stack_base, int tid, uint32_t& nbox, uint32_t& ntri)
+//
+// Per-lane traversal stack: the first LDS_DEPTH entries live in LDS, laid out [entry][lane] so that a
+// wave's push or pop is one contiguous 512-byte row (no bank conflicts); deeper entries spill to
+// private memory. The loop is "descend until a leaf, then test the leaf": lanes of a wave spend
+// their iterations in the same kind of work.
+constexpr int kLdsDepth = 16;
+constexpr int kSpillDepth = 48;
+#define PT_TRAV_EMPTY ((int)0x80000000)
+
+template <int BLOCK, int LDS_DEPTH, bool COUNT>
+PT_DEV Hit closest_hit(const DScene& S, F3 o, F3 d, int tid, uint32_t& nbox, uint32_t& ntri)
 {
+    __shared__ uint2 s_stack[LDS_DEPTH * BLOCK];
+    uint2 spill[kSpillDepth];
+    int sp = 0;
     Hit best; best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
     if (!finite3(o) || !finite3(d)) return best;
     F3 inv = 1.0f / d;
     if (COUNT) nbox += 1;
     float troot = box_entry(o, inv, S.root_min, S.root_max);
     if (!(troot < best.t)) return best;
-    TravStack<BLOCK> st;
-    st.init(stack_base, tid);
     int cur = S.root_ref;
+
+    auto push = [&](int ref, float tn) {
+        uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
+        if (sp < LDS_DEPTH) s_stack[sp * BLOCK + tid] = e;
+        else if (sp - LDS_DEPTH < kSpillDepth) spill[sp - LDS_DEPTH] = e;
+        sp++;
+    };
+    auto pop_valid = [&]() -> int {
+        while (sp > 0) {
+            sp--;
+            uint2 e;
+            if (sp < LDS_DEPTH) e = s_stack[sp * BLOCK + tid];
+            else {
+                e = spill[(sp - LDS_DEPTH) < kSpillDepth ? (sp - LDS_DEPTH) : (kSpillDepth - 1)];
+                // keeps the two loads in separate blocks: merged, they become one generic-pointer load
+                asm volatile("" : "+v"(e.x), "+v"(e.y));
+            }
+            if (__uint_as_float(e.y) < best.t) return (int)e.x;
+        }
+        return PT_TRAV_EMPTY;
+    };
+
     for (;;) {
-        if (cur >= 0) {
+        while (cur >= 0) {
             const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
             float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
@@ -248,9 +252,12 @@ PT_DEV Hit closest_hit(const DScene& S, F3 o, F3 d, uint2* stack_base, int tid, 
             int nearR, farR; float dn, df;
             if (dl > dr) { nearR = right; dn = dr; farR = left; df = dl; }
             else         { nearR = left;  dn = dl; farR = right; df = dr; }
-            if (df < best.t) st.push(farR, df);
-            if (dn < best.t) { cur = nearR; continue; }
-        } else {
+            if (df < best.t) push(farR, df);
+            if (dn < best.t) cur = nearR;
+            else cur = pop_valid();
+        }
+        if (cur == PT_TRAV_EMPTY) break;
+        {
             const DTri* tp = S.tris + (~cur);
             int count = 1;
             for (int i = 0; i < count; i++) {
@@ -264,12 +271,8 @@ PT_DEV Hit closest_hit(const DScene& S, F3 o, F3 d, uint2* stack_base, int tid, 
                 best.t = t; best.tri = id; best.u = u; best.v = v;
             }
         }
-        bool found = false;
-        while (st.sp > 0) {
-            StackEntry e = st.pop();
-            if (e.tn < best.t) { cur = e.ref; found = true; break; }
-        }
-        if (!found) break;
+        cur = pop_valid();
+        if (cur == PT_TRAV_EMPTY) break;
     }
     return best;
 }

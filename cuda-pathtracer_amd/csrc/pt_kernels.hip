@@ -14,13 +14,12 @@ __global__ __launch_bounds__(256) void trace_closest_kernel(DScene S, const pt_r
                                                             pt_hit* __restrict__ hits, uint32_t* __restrict__ nbox_out,
                                                             uint32_t* __restrict__ ntri_out)
 {
-    __shared__ uint2 stack[kLdsDepth * 256];
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const float4* rp = reinterpret_cast<const float4*>(rays + i);
     float4 r0 = rp[0], r1 = rp[1];
     uint32_t nb = 0, nt = 0;
-    Hit h = closest_hit<256, COUNT>(S, f3(r0.x, r0.y, r0.z), f3(r1.x, r1.y, r1.z), stack, threadIdx.x, nb, nt);
+    Hit h = closest_hit<256, kLdsDepth, COUNT>(S, f3(r0.x, r0.y, r0.z), f3(r1.x, r1.y, r1.z), threadIdx.x, nb, nt);
     pt_hit out; out.t = h.t; out.tri = h.tri;
     hits[i] = out;
     if (COUNT) { nbox_out[i] = nb; ntri_out[i] = nt; }
@@ -45,7 +44,6 @@ template <bool COUNT>
 __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera cam, int frame_begin, int frame_end,
                                                             float* __restrict__ accum, DCounters* __restrict__ ctr)
 {
-    __shared__ uint2 stack[kLdsDepth * 64];
     int tiles_x = (cam.W + 7) >> 3;
     int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     int x = tx * 8 + (threadIdx.x & 7), y = ty * 8 + (threadIdx.x >> 3);
@@ -61,7 +59,7 @@ __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera ca
         F3 color = f3(0.f, 0.f, 0.f);
         if (!cam.is_rendering) {
             // preview: pathtracer.cu:504-525
-            Hit h = closest_hit<64, COUNT>(S, P.o, P.d, stack, threadIdx.x, tl.box, tl.tri);
+            Hit h = closest_hit<64, kLdsDepth, COUNT>(S, P.o, P.d, threadIdx.x, tl.box, tl.tri);
             if (COUNT) tl.rays++;
             Surf info;
             resolve_hit<COUNT>(S, h, P.d, info, tl.taps, tl.taps_r);
@@ -81,7 +79,7 @@ __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera ca
                 bool shadow = P.state == ST_SHADOW;
                 F3 ro = shadow ? P.so : P.o;
                 F3 rd = shadow ? P.sd : P.d;
-                Hit h = closest_hit<64, COUNT>(S, ro, rd, stack, threadIdx.x, tl.box, tl.tri);
+                Hit h = closest_hit<64, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
                 if (COUNT) tl.rays++;
                 Surf info;
                 resolve_hit<COUNT>(S, h, rd, info, tl.taps, tl.taps_r);

@@ -7,5 +7,8 @@ namespace ptamd {
 void launch_trace_closest(const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, uint32_t* nbox_dev, uint32_t* ntri_dev, hipStream_t stream);
 void launch_render_samples(const DScene& S, const DCamera& cam, int frame_begin, int frame_end, float* accum_dev, DCounters* ctr_dev, hipStream_t stream);
 void launch_resolve_display(const float* accum_dev, int n_pixels, int n_frames, uint8_t* rgba_dev, hipStream_t stream);
+void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, hipStream_t s);
+void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t ext0, hipEvent_t ext1);
+void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, hipStream_t s);
 void launch_detmath_probe(const float* x_dev, const float* y_dev, int n, float* out_dev, hipStream_t stream);
 }

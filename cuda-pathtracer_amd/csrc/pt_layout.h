@@ -64,4 +64,21 @@ struct DCounters {
     unsigned long long rays, samples, box_tests, tri_tests, shade_vertices, env_samples, tex_taps, tex_taps_r;
 };
 
+// ---------------------------------------------------------------- wavefront pool
+// Path slots as a structure of 16-byte arrays (slot-indexed) plus the per-sample staging values.
+enum : int { WF_CTR_NEXT_SAMPLE = 0, WF_CTR_BSDF_COUNT = 1, WF_CTR_LIVE = 2, WF_CTR_LIVE_PREV = 3, WF_CTR_WORDS = 8 };
+struct WfParams {
+    float4 *ray_o, *ray_d;          // pending ray; ray_d.w != 0 when the slot has a ray to trace
+    float4 *hit;                    // (t, triangle, u, v)
+    float4 *c0, *c1, *c2;           // (o, thr) (d, pdf) (result, flags, draws, sample id)
+    float4 *d0, *d1;                // (transmittance, light pdf) (light radiance, bounce)
+    float4 *e0, *e1, *e2, *e3, *e4; // vertex context: material values and shading normal
+    uint32_t* bsdf_queue;
+    uint32_t* counters;
+    float* staging;                 // n_frames * W * H sample values of the current chunk
+    int n_slots;
+    uint32_t n_samples;
+    int W, H, tiled, frame_begin, n_frames;
+};
+
 } // namespace ptamd

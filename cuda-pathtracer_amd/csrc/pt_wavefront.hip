@@ -147,8 +147,8 @@ PT_DEV uint32_t wave_take(uint32_t* counter, bool need)
 template <bool COUNT>
 PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_t slot, Path& P, uint32_t& sample, SampleId& id, bool finished, uint32_t& nsamples)
 {
-    // bounded: a fresh sample is only born finished when its channel draw is exactly 1.0
-    for (int round = 0; round < 4; round++) {
+    // loops only while some fresh sample is born finished (its channel draw was exactly 1.0: 3e-8)
+    for (;;) {
         if (finished) {
             float v = P.result * 3.f;
             w.staging[id.stage_index] = v > 0.f ? v : 0.f;
@@ -231,14 +231,13 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S, DCounters* ctr)
 {
-    __shared__ uint2 stack[kLdsDepth * kBlock];
     uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= (uint32_t)w.n_slots) return;
     float4 rd = w.ray_d[slot];
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
     if (__float_as_int(rd.w) != 0) {
         float4 ro = w.ray_o[slot];
-        Hit h = closest_hit<kBlock, COUNT>(S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), stack, threadIdx.x, tl.box, tl.tri);
+        Hit h = closest_hit<kBlock, kLdsDepth, COUNT>(S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), threadIdx.x, tl.box, tl.tri);
         if (COUNT) tl.rays++;
         w.hit[slot] = make_float4(h.t, __uint_as_float(h.tri), h.u, h.v);
     }
@@ -368,16 +367,18 @@ void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, h
     else hipLaunchKernelGGL(wf_generate_kernel<false>, grid, block, 0, s, w, cam, ctr);
 }
 
-void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s)
+void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t ext0, hipEvent_t ext1)
 {
     dim3 grid((w.n_slots + kBlock - 1) / kBlock), block(kBlock);
     hipLaunchKernelGGL(wf_reset_iteration_kernel, dim3(1), dim3(1), 0, s, w.counters);
+    if (ext0) (void)hipEventRecord(ext0, s);
+    if (ctr) hipLaunchKernelGGL(wf_extend_kernel<true>, grid, block, 0, s, w, S, ctr);
+    else hipLaunchKernelGGL(wf_extend_kernel<false>, grid, block, 0, s, w, S, ctr);
+    if (ext1) (void)hipEventRecord(ext1, s);
     if (ctr) {
-        hipLaunchKernelGGL(wf_extend_kernel<true>, grid, block, 0, s, w, S, ctr);
         hipLaunchKernelGGL(wf_shade_kernel<true>, grid, block, 0, s, w, S, cam, ctr);
         hipLaunchKernelGGL(wf_bsdf_kernel<true>, grid, block, 0, s, w, S, cam, ctr);
     } else {
-        hipLaunchKernelGGL(wf_extend_kernel<false>, grid, block, 0, s, w, S, ctr);
         hipLaunchKernelGGL(wf_shade_kernel<false>, grid, block, 0, s, w, S, cam, ctr);
         hipLaunchKernelGGL(wf_bsdf_kernel<false>, grid, block, 0, s, w, S, cam, ctr);
     }

@@ -14,13 +14,14 @@ LIB_PATH = os.path.join(_PKG, 'libptamd.so')
 
 PT_SKY_ENVMAP, PT_SKY_SUNSKY = 0, 1
 PT_BVH_REFERENCE = 0
+PT_MODE_WAVEFRONT, PT_MODE_SINGLE_KERNEL = 0, 1
 
 EXPORTS = [
     'pt_last_error', 'pt_create', 'pt_destroy', 'pt_set_stream', 'pt_init', 'pt_clear_accum', 'pt_upload_triangles',
     'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_upload_texture', 'pt_upload_envmap',
-    'pt_set_sky_mode', 'pt_set_max_bounces', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
+    'pt_set_sky_mode', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
     'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_trace_closest', 'pt_trace_closest_dev',
-    'pt_trace_closest_counted', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_scene_bytes',
+    'pt_trace_closest_counted', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
     'pt_detmath_probe', 'pt_read_obj', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
     'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
     'pt_host_build_bvh', 'pt_load_hdr', 'pt_build_env_cdf', 'pt_free', 'pt_camera_basis',
@@ -188,6 +189,12 @@ class Renderer:
     def set_sky_mode(self, mode):
         check(lib().pt_set_sky_mode(self.h, C.c_int(mode)))
 
+    def set_mode(self, mode):
+        check(lib().pt_set_mode(self.h, C.c_int(mode)))
+
+    def set_pool(self, slots, chunk_frames=64):
+        check(lib().pt_set_pool(self.h, C.c_int(slots), C.c_int(chunk_frames)))
+
     def set_max_bounces(self, n):
         check(lib().pt_set_max_bounces(self.h, C.c_int(n)))
 
@@ -258,6 +265,12 @@ class Renderer:
 
     def reset_counters(self):
         check(lib().pt_reset_counters(self.h))
+
+    def stage_timing(self, on):
+        """Returns (extend_ms, extend_launches) accumulated since the last call, then sets timing on/off."""
+        ms, n = C.c_double(), C.c_uint64()
+        check(lib().pt_stage_timing(self.h, C.c_int(1 if on else 0), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def scene_bytes(self):
         a, b = C.c_uint64(), C.c_uint64()

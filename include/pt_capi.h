@@ -35,6 +35,10 @@ extern "C" {
 #define PT_SKY_ENVMAP    0
 #define PT_SKY_SUNSKY    1
 
+/* how pt_render_headless / pt_render_frame schedule the work */
+#define PT_MODE_WAVEFRONT     0   /* stage kernels over a pool of path slots (default) */
+#define PT_MODE_SINGLE_KERNEL 1   /* one kernel, one pixel per lane, as pathtracer.cu:544-606 launches it */
+
 /* BVH build flavours for pt_host_build_bvh / pt_build_bvh */
 #define PT_BVH_REFERENCE 0   /* identical tree to BVH_builder.cpp:12-128, built with binned sweeps */
 
@@ -151,6 +155,8 @@ int pt_upload_envmap(pt_ctx* ctx, const float* rgba, const float* cdf, int w, in
 int pt_set_sky_mode(pt_ctx* ctx, int mode);
 
 /* ---- headless rendering (replaces the window loop, main.cpp:247-296) ---- */
+int pt_set_mode(pt_ctx* ctx, int mode);                                 /* PT_MODE_*; both modes give identical accumulators */
+int pt_set_pool(pt_ctx* ctx, int slots, int chunk_frames);              /* wavefront pool size and frames per staging chunk */
 int pt_set_max_bounces(pt_ctx* ctx, int max_bounces);                   /* pathtracer.cu:405 hard-codes 512 */
 int pt_render_headless(pt_ctx* ctx, const pt_params* params, int frame_begin, int frame_end); /* frames [begin,end): accum as pathtracer.cu:583-586, first frame overwrites */
 int pt_read_accum(pt_ctx* ctx, float* rgb_out);                         /* 3*W*H floats */
@@ -170,6 +176,7 @@ int pt_trace_closest_counted(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hit
 int pt_get_counters(pt_ctx* ctx, pt_counters* out);
 int pt_reset_counters(pt_ctx* ctx);
 int pt_enable_counters(pt_ctx* ctx, int on);                            /* instrumented kernels (slower); off by default */
+int pt_stage_timing(pt_ctx* ctx, int on, double* extend_ms_out, uint64_t* extend_launches_out); /* HIP-event time of the extend kernel: returns the totals since the last call, then switches timing on/off and clears them */
 int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* tri_bytes); /* size of the flattened BVH in HBM */
 int pt_detmath_probe(pt_ctx* ctx, const float* x, const float* y, int n, float* out12); /* device evaluation of include/pt_detmath.h, 12 results per input pair */
 

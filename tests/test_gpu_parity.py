@@ -86,8 +86,14 @@ def test_non_finite_rays_miss():
     r.close()
 
 
-def _render_both(b, P, f0, f1, bounces):
+MODES = [pytest.param(0, id='wavefront'), pytest.param(1, id='single_kernel')]
+
+
+def _render_both(b, P, f0, f1, bounces, mode=0, pool=None):
     r = b.renderer(P)
+    r.set_mode(mode)
+    if pool is not None:
+        r.set_pool(*pool)
     r.set_max_bounces(bounces)
     r.enable_counters(True)
     r.render(P, f0, f1)
@@ -106,10 +112,11 @@ def _assert_radiance(acc, want):
         raise AssertionError('%d of %d accumulator words differ; worst relative error %g' % (bad, same.size, rel_err(acc, want)))
 
 
-def test_cornell_radiance_matches_oracle():
+@pytest.mark.parametrize('mode', MODES)
+def test_cornell_radiance_matches_oracle(mode):
     b = util.cornell('black')
     P = scenes.cornell_params(ptamd.default_params(64, 64))
-    acc, ctr, img, want, st = _render_both(b, P, 0, 8, 4)
+    acc, ctr, img, want, st = _render_both(b, P, 0, 8, 4, mode)
     _assert_radiance(acc, want)
     for k in ('rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps', 'tex_taps_r'):
         assert ctr[k] == st[k], k
@@ -117,19 +124,21 @@ def test_cornell_radiance_matches_oracle():
     assert want.sum() > 0
 
 
-def test_cornell_with_sky_light_long_paths():
+@pytest.mark.parametrize('mode', MODES)
+def test_cornell_with_sky_light_long_paths(mode):
     b = util.cornell('sky')
     P = scenes.cornell_params(ptamd.default_params(48, 48))
-    acc, ctr, img, want, st = _render_both(b, P, 3, 7, 512)
+    acc, ctr, img, want, st = _render_both(b, P, 3, 7, 512, mode)
     _assert_radiance(acc, want)
     assert ctr['rays'] == st['rays']
     assert np.array_equal(img, orc.resolve_display(want, 4))
 
 
-def test_atrium_radiance_matches_oracle():
+@pytest.mark.parametrize('mode', MODES)
+def test_atrium_radiance_matches_oracle(mode):
     b = util.atrium(detail=0.35, env_size=(256, 128))
     P = scenes.atrium_params(ptamd.default_params(96, 56))
-    acc, ctr, img, want, st = _render_both(b, P, 0, 2, 512)
+    acc, ctr, img, want, st = _render_both(b, P, 0, 2, 512, mode)
     _assert_radiance(acc, want)
     for k in ('rays', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps', 'tex_taps_r'):
         assert ctr[k] == st[k] and st[k] > 0, k
@@ -137,26 +146,40 @@ def test_atrium_radiance_matches_oracle():
     assert np.array_equal(img, orc.resolve_display(want, 2))
 
 
-def test_thin_lens_and_preview_modes():
+@pytest.mark.parametrize('mode', MODES)
+def test_thin_lens_and_preview_modes(mode):
     b = util.cornell('sky')
     P = scenes.cornell_params(ptamd.default_params(40, 40))
     P.DOF_strenght = 4.0
     P.focalDistance = 300.0
-    acc, _, _, want, _ = _render_both(b, P, 0, 3, 6)
+    acc, _, _, want, _ = _render_both(b, P, 0, 3, 6, mode)
     _assert_radiance(acc, want)
     P.DOF_strenght = 0.0
     P.isRendering = 0
-    acc, _, _, want, _ = _render_both(b, P, 0, 1, 6)
+    acc, _, _, want, _ = _render_both(b, P, 0, 1, 6, mode)
     _assert_radiance(acc, want)
 
 
-def test_sun_sky_mode_glossy_dielectric():
+@pytest.mark.parametrize('mode', MODES)
+def test_sun_sky_mode_glossy_dielectric(mode):
     b = util.atrium(detail=0.3, env_size=(64, 32), glossy=0.3, glass=0.2, sky_mode=1)
     P = scenes.atrium_params(ptamd.default_params(64, 40))
-    acc, ctr, img, want, st = _render_both(b, P, 0, 2, 16)
+    acc, ctr, img, want, st = _render_both(b, P, 0, 2, 16, mode)
     _assert_radiance(acc, want)
     assert ctr['env_samples'] == 0 and st['env_samples'] == 0
     assert ctr['rays'] == st['rays']
+
+
+@pytest.mark.parametrize('pool', [(64, 1), (320, 3), (1 << 14, 64)])
+def test_wavefront_pool_size_does_not_change_results(pool):
+    """Tiny pools force slot regeneration, retirement and several staging chunks; odd image size
+    exercises the row-major sample order."""
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(37, 29))
+    acc, ctr, img, want, st = _render_both(b, P, 1, 6, 12, 0, pool)
+    _assert_radiance(acc, want)
+    for k in ('rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps', 'tex_taps_r'):
+        assert ctr[k] == st[k], k
 
 
 def test_render_frame_matches_reference_frame_loop():
