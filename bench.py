@@ -49,6 +49,7 @@ def main():
     ap.add_argument('--cpu-spp', type=int, default=1)
     ap.add_argument('--mode', choices=['wavefront', 'single_kernel'], default='wavefront')
     ap.add_argument('--pool', type=int, default=0, help='wavefront pool slots (0 = library default)')
+    ap.add_argument('--tune', type=str, default='', help='refill_lanes,leaf_vote,blocks_per_cu for the traversal kernel')
     args = ap.parse_args()
 
     import torch
@@ -80,6 +81,8 @@ def main():
     r.set_mode(0 if args.mode == 'wavefront' else 1)
     if args.pool:
         r.set_pool(args.pool, 64)
+    if args.tune:
+        r.set_extend_tuning(*[int(x) for x in args.tune.split(',')])
     stream = torch.cuda.current_stream()
     r.set_stream(stream.cuda_stream)
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device='cuda')

@@ -57,6 +57,7 @@ struct pt_ctx {
     int mode = PT_MODE_WAVEFRONT;
     int pool_slots = 1 << 21;
     int chunk_frames = 64;
+    int refill_lanes = 24, leaf_vote = 24, extend_blocks_per_cu = 5, n_cus = 256;
     void* wf_block = nullptr;       // one allocation holding every slot array
     size_t wf_block_bytes = 0;
     float* wf_staging = nullptr;
@@ -89,6 +90,7 @@ int pt_create(pt_ctx** out, int device_id)
     pt_ctx* c = new (std::nothrow) pt_ctx();
     if (!c) { set_error("out of memory"); return PT_ERR_NOMEM; }
     c->device = device_id;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cus = prop.multiProcessorCount; }
     HIP_TRY(hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking));
     c->stream = c->own_stream;
     HIP_TRY(hipEventCreate(&c->ev0));
@@ -466,7 +468,8 @@ static int wf_prepare(pt_ctx* c, int frames, WfParams* w)
         c->wf_staging_bytes = sbytes;
     }
     if (!c->wf_counters) {
-        HIP_TRY(hipMalloc((void**)&c->wf_counters, WF_CTR_WORDS * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc((void**)&c->wf_counters, WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->wf_counters, 0, WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long)));
         HIP_TRY(hipHostMalloc((void**)&c->wf_host_counters, WF_CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
     }
     float4* base = (float4*)c->wf_block;
@@ -480,6 +483,8 @@ static int wf_prepare(pt_ctx* c, int frames, WfParams* w)
     w->W = c->W; w->H = c->H;
     w->tiled = (c->W % 8 == 0 && c->H % 8 == 0) ? 1 : 0;
     w->n_frames = frames;
+    w->refill_lanes = c->refill_lanes; w->leaf_vote = c->leaf_vote;
+    w->extend_blocks = c->extend_blocks_per_cu * c->n_cus;
     return PT_OK;
 }
 
@@ -526,6 +531,22 @@ int pt_stage_timing(pt_ctx* c, int on, double* extend_ms_out, uint64_t* extend_l
     if (extend_launches_out) *extend_launches_out = c->extend_launches;
     c->stage_timing = on != 0;
     c->extend_ms = 0.0; c->extend_launches = 0;
+    return PT_OK;
+}
+
+// diagnostic builds only: the 16 debug words the extend kernel accumulates (zeroed on read)
+int pt_debug_words(pt_ctx* c, unsigned long long* out16)
+{
+    if (!c || !out16 || !c->wf_counters) { set_error("pt_debug_words: nothing to read"); return PT_ERR_STATE; }
+    HIP_TRY(hipMemcpy(out16, c->wf_counters + WF_CTR_WORDS, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(c->wf_counters + WF_CTR_WORDS, 0, 16 * sizeof(unsigned long long)));
+    return PT_OK;
+}
+
+int pt_set_extend_tuning(pt_ctx* c, int refill_lanes, int leaf_vote, int blocks_per_cu)
+{
+    if (!c || refill_lanes < 1 || refill_lanes > 64 || leaf_vote < 1 || leaf_vote > 64 || blocks_per_cu < 1 || blocks_per_cu > 5) { set_error("pt_set_extend_tuning: bad argument"); return PT_ERR_ARG; }
+    c->refill_lanes = refill_lanes; c->leaf_vote = leaf_vote; c->extend_blocks_per_cu = blocks_per_cu;
     return PT_OK;
 }
 

@@ -66,7 +66,7 @@ struct DCounters {
 
 // ---------------------------------------------------------------- wavefront pool
 // Path slots as a structure of 16-byte arrays (slot-indexed) plus the per-sample staging values.
-enum : int { WF_CTR_NEXT_SAMPLE = 0, WF_CTR_BSDF_COUNT = 1, WF_CTR_LIVE = 2, WF_CTR_LIVE_PREV = 3, WF_CTR_WORDS = 8 };
+enum : int { WF_CTR_NEXT_SAMPLE = 0, WF_CTR_BSDF_COUNT = 1, WF_CTR_LIVE = 2, WF_CTR_LIVE_PREV = 3, WF_CTR_RAY_NEXT = 4, WF_CTR_WORDS = 8 };
 struct WfParams {
     float4 *ray_o, *ray_d;          // pending ray; ray_d.w != 0 when the slot has a ray to trace
     float4 *hit;                    // (t, triangle, u, v)
@@ -79,6 +79,7 @@ struct WfParams {
     int n_slots;
     uint32_t n_samples;
     int W, H, tiled, frame_begin, n_frames;
+    int refill_lanes, leaf_vote, extend_blocks;   // extend-kernel tuning (see wf_extend_kernel)
 };
 
 } // namespace ptamd

@@ -228,19 +228,199 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
 }
 
 // ---------------------------------------------------------------- extend
+// Persistent waves over the pool's rays. Traversal lengths vary by more than 10x between rays, so a
+// wave that kept its 64 rays until the last one finished would run mostly empty (measured: about 6
+// of 64 lanes busy). Here a lane whose ray is finished takes the next untraced ray from a global
+// counter (one atomic per wave per refill) as soon as kRefillLanes lanes are idle, and leaf work is
+// postponed until kLeafVote lanes wait at a leaf (or nobody can descend), so each pass of the loop
+// does one kind of work for most lanes. The per-ray visiting order, and therefore the result and the
+// test counts, are exactly those of closest_hit().
+#ifndef PT_REFILL
+#define PT_REFILL 24
+#endif
+#ifndef PT_LEAFVOTE
+#define PT_LEAFVOTE 24
+#endif
+#ifndef PT_EXT_LDS
+#define PT_EXT_LDS 16
+#endif
+#ifndef PT_EXT_BLOCKS_PER_CU
+#define PT_EXT_BLOCKS_PER_CU 5
+#endif
+#ifndef PT_SPLIT_NODE_LOAD
+#define PT_SPLIT_NODE_LOAD 0
+#endif
+#ifndef PT_STAMPS
+#define PT_STAMPS 0      // diagnostic build: per-section cycle stamps in the extend kernel
+#endif
+constexpr int kRayChunk = 256;
+constexpr int kRefillLanes = PT_REFILL;
+constexpr int kLeafVote = PT_LEAFVOTE;
+constexpr int kExtendLds = PT_EXT_LDS;
+constexpr int kExtendBlocks = 256 * PT_EXT_BLOCKS_PER_CU;      // 256 CUs x the workgroups that fit one CU's LDS
+
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S, DCounters* ctr)
 {
-    uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    if (slot >= (uint32_t)w.n_slots) return;
-    float4 rd = w.ray_d[slot];
+    __shared__ uint2 s_stack[kExtendLds * kBlock];
+    uint2 spill[kSpillDepth];
+    const int tid = (int)threadIdx.x;
+    int cur = PT_TRAV_EMPTY, sp = 0;
+    uint32_t slot = 0;
+    F3 o = f3(0.f, 0.f, 0.f), d = o, inv = o;
+    Hit best; best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
+    bool has_ray = false;
+    bool more = true;
+    uint32_t chunk_next = 0, chunk_end = 0;      // wave-uniform
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
-    if (__float_as_int(rd.w) != 0) {
-        float4 ro = w.ray_o[slot];
-        Hit h = closest_hit<kBlock, kLdsDepth, COUNT>(S, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z), threadIdx.x, tl.box, tl.tri);
-        if (COUNT) tl.rays++;
-        w.hit[slot] = make_float4(h.t, __uint_as_float(h.tri), h.u, h.v);
+
+    auto push = [&](int ref, float tn) {
+        uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
+        if (sp < kExtendLds) s_stack[sp * kBlock + tid] = e;
+        else if (sp - kExtendLds < kSpillDepth) spill[sp - kExtendLds] = e;
+        sp++;
+    };
+    auto pop_valid = [&]() -> int {
+        while (sp > 0) {
+            sp--;
+            uint2 e;
+            if (sp < kExtendLds) e = s_stack[sp * kBlock + tid];
+            else {
+                e = spill[(sp - kExtendLds) < kSpillDepth ? (sp - kExtendLds) : (kSpillDepth - 1)];
+                asm volatile("" : "+v"(e.x), "+v"(e.y));    // keep the LDS and the private load apart
+            }
+            if (__uint_as_float(e.y) < best.t) return (int)e.x;
+        }
+        return PT_TRAV_EMPTY;
+    };
+    auto retire = [&]() {      // the ray of this lane is finished: publish its hit
+        w.hit[slot] = make_float4(best.t, __uint_as_float(best.tri), best.u, best.v);
+        has_ray = false;
+    };
+
+#if PT_STAMPS
+    unsigned long long st_refill = 0, st_load = 0, st_box = 0, st_leaf = 0, st_iters = 0, st_lanes = 0, st_leafphases = 0, st_t;
+#define STAMP(acc) do { unsigned long long n__ = __builtin_amdgcn_s_memtime(); acc += n__ - st_t; st_t = n__; } while (0)
+    st_t = __builtin_amdgcn_s_memtime();
+#else
+#define STAMP(acc) do { } while (0)
+#endif
+    for (;;) {
+        bool idle = !has_ray;
+        int n_idle = __popcll(__ballot(idle));
+        if (more && n_idle >= w.refill_lanes) {
+            // rays are handed out from a wave-private chunk of consecutive slots; one global atomic per
+            // chunk (a single counter word serves only about 90 atomics per microsecond chip-wide)
+            if (chunk_next >= chunk_end) {
+                uint32_t c = 0;
+                if ((tid & 63) == 0) c = atomicAdd(w.counters + WF_CTR_RAY_NEXT, (uint32_t)kRayChunk);
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                chunk_next = c;
+                chunk_end = c + kRayChunk < (uint32_t)w.n_slots ? c + kRayChunk : (uint32_t)w.n_slots;
+                if (c >= (uint32_t)w.n_slots) { more = false; chunk_end = chunk_next; }
+            }
+            unsigned long long idle_mask = __ballot(idle);
+            uint32_t avail = chunk_end - chunk_next;
+            uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << (tid & 63)) - 1ull));
+            bool got = idle && rank < avail;
+            uint32_t idx = chunk_next + rank;
+            uint32_t taken = (uint32_t)__popcll(idle_mask);
+            chunk_next += taken < avail ? taken : avail;
+            if (got) {
+                float4 rd = w.ray_d[idx];
+                if (__float_as_int(rd.w) != 0) {
+                    float4 ro = w.ray_o[idx];
+                    slot = idx;
+                    o = f3(ro.x, ro.y, ro.z); d = f3(rd.x, rd.y, rd.z);
+                    best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
+                    sp = 0;
+                    has_ray = true;
+                    if (COUNT) tl.rays++;
+                    cur = PT_TRAV_EMPTY;
+                    if (finite3(o) && finite3(d)) {
+                        inv = 1.0f / d;
+                        if (COUNT) tl.box += 1;
+                        float troot = box_entry(o, inv, S.root_min, S.root_max);
+                        if (troot < best.t) cur = S.root_ref;
+                    }
+                    if (cur == PT_TRAV_EMPTY) retire();
+                }
+            }
+            n_idle = __popcll(__ballot(!has_ray));
+        }
+        if (n_idle == 64 || (!more && !__any(has_ray))) {
+            if (!more) break;
+            continue;
+        }
+        STAMP(st_refill);
+#if PT_STAMPS
+        st_iters++; st_lanes += __popcll(__ballot(has_ray && cur >= 0));
+#endif
+        // ---- one interior step for every descending lane
+        if (has_ray && cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+            float4 n0 = np[0];
+#if PT_SPLIT_NODE_LOAD
+            // The four 16-byte loads of a node go to one cache line. Issued back to back, the last three
+            // queue in the L1 behind the miss of the first and stall its pipeline for every wave of the
+            // CU; waiting for the first makes them plain hits.
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w) :: "memory");
+#endif
+            float4 n1 = np[1], n2 = np[2], n3 = np[3];
+#if PT_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(n1.x), "+v"(n2.x), "+v"(n3.x), "+v"(n3.y) :: "memory");
+#endif
+            float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
+            float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
+            int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
+            float dl = box_entry(o, inv, lmin, lmax);
+            float dr = box_entry(o, inv, rmin, rmax);
+            if (COUNT) tl.box += 2;
+            int nearR, farR; float dn, df;
+            if (dl > dr) { nearR = right; dn = dr; farR = left; df = dl; }
+            else         { nearR = left;  dn = dl; farR = right; df = dr; }
+            if (df < best.t) push(farR, df);
+            if (dn < best.t) cur = nearR;
+            else { cur = pop_valid(); if (cur == PT_TRAV_EMPTY) retire(); }
+        }
+#if PT_STAMPS
+        {   // split the interior step into "until the node arrived" and "the rest": re-stamp is approximate (whole step here)
+            STAMP(st_box);
+        }
+#endif
+        // ---- leaf work, once enough lanes wait at a leaf or nobody can descend
+        bool at_leaf = has_ray && cur < 0;
+        unsigned long long leaf_mask = __ballot(at_leaf);
+        if (leaf_mask != 0ull && (__popcll(leaf_mask) >= w.leaf_vote || !__any(has_ray && cur >= 0))) {
+            if (at_leaf) {
+                const DTri* tp = S.tris + (~cur);
+                int count = 1;
+                for (int i = 0; i < count; i++) {
+                    float4 q0 = tp[i].q0, q1 = tp[i].q1, q2 = tp[i].q2;
+                    if (i == 0) count = __float_as_int(q1.w);
+                    uint32_t id = __float_as_uint(q0.w);
+                    float t, u, v;
+                    if (COUNT) tl.tri += 1;
+                    if (!tri_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), o, d, best.t, t, u, v)) continue;
+                    if (best.tri != PT_NO_TRI && t == best.t && id > best.tri) continue;
+                    best.t = t; best.tri = id; best.u = u; best.v = v;
+                }
+                cur = pop_valid();
+                if (cur == PT_TRAV_EMPTY) retire();
+            }
+#if PT_STAMPS
+            st_leafphases++;
+#endif
+        }
+        STAMP(st_leaf);
     }
+#if PT_STAMPS
+    if ((threadIdx.x & 63) == 0) {
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(w.counters + WF_CTR_WORDS);
+        atomicAdd(dbg + 0, st_refill); atomicAdd(dbg + 1, st_box); atomicAdd(dbg + 2, st_leaf); atomicAdd(dbg + 3, st_iters);
+        atomicAdd(dbg + 4, st_lanes); atomicAdd(dbg + 5, st_leafphases); atomicAdd(dbg + 6, 1ull);
+    }
+#endif
     flush_tally<COUNT>(ctr, tl, 0);
 }
 
@@ -358,6 +538,7 @@ __global__ void wf_reset_iteration_kernel(uint32_t* counters)
     counters[WF_CTR_LIVE_PREV] = counters[WF_CTR_LIVE];
     counters[WF_CTR_LIVE] = 0;
     counters[WF_CTR_BSDF_COUNT] = 0;
+    counters[WF_CTR_RAY_NEXT] = 0;
 }
 
 void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, hipStream_t s)
@@ -372,8 +553,11 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
     dim3 grid((w.n_slots + kBlock - 1) / kBlock), block(kBlock);
     hipLaunchKernelGGL(wf_reset_iteration_kernel, dim3(1), dim3(1), 0, s, w.counters);
     if (ext0) (void)hipEventRecord(ext0, s);
-    if (ctr) hipLaunchKernelGGL(wf_extend_kernel<true>, grid, block, 0, s, w, S, ctr);
-    else hipLaunchKernelGGL(wf_extend_kernel<false>, grid, block, 0, s, w, S, ctr);
+    // persistent waves: enough workgroups to fill every CU, each pulls rays until the pool is drained
+    int ext_blocks = (w.n_slots + kBlock - 1) / kBlock;
+    if (ext_blocks > w.extend_blocks) ext_blocks = w.extend_blocks;
+    if (ctr) hipLaunchKernelGGL(wf_extend_kernel<true>, dim3(ext_blocks), block, 0, s, w, S, ctr);
+    else hipLaunchKernelGGL(wf_extend_kernel<false>, dim3(ext_blocks), block, 0, s, w, S, ctr);
     if (ext1) (void)hipEventRecord(ext1, s);
     if (ctr) {
         hipLaunchKernelGGL(wf_shade_kernel<true>, grid, block, 0, s, w, S, cam, ctr);

@@ -279,6 +279,8 @@ HitRec closest_brute(const Scene& S, V3 o, V3 d)
     return best;
 }
 
+unsigned long long* g_depth_hist = nullptr;     // optional: histogram of stack depth at each push (diagnostics)
+
 // pathtracer.cu:185-234 (BVHIntersect) with D2 and D6: same visiting order (nearer child first,
 // farther child deferred, a deferred node dropped when its entry distance no longer beats the
 // current hit), triangle index carried, ties to the lowest index.
@@ -318,6 +320,7 @@ HitRec closest_bvh(const Scene& S, V3 o, V3 d, Stats* st)
             if (df < best.t) {
                 if (sp >= 64) { fprintf(stderr, "oracle: traversal stack overflow\n"); abort(); }
                 stack[sp++] = Entry{farN, df};
+                if (g_depth_hist) __atomic_fetch_add(&g_depth_hist[sp], 1ull, __ATOMIC_RELAXED);
             }
             if (dn < best.t) cur = nearN;
         }
@@ -1308,6 +1311,8 @@ void orc_detmath_probe(const float* x, const float* y, int n, float* out)
         o[8] = 1.0f / a; o[9] = __builtin_sqrtf(a); o[10] = a / b; o[11] = (float)pt_dm_pow((double)a, (double)b);
     }
 }
+
+void orc_set_depth_histogram(unsigned long long* hist65) { g_depth_hist = hist65; }
 
 int orc_max_threads(void)
 {
