@@ -46,6 +46,7 @@ struct pt_ctx {
     std::vector<float*> tex_data;
     float* d_env = nullptr;
     float* d_cdf = nullptr;
+    float* d_env_tables = nullptr;   // row table [H] followed by column table [H*W]
     DScene scene{};
     bool have_tris = false, have_bvh = false, have_mats = false, have_env = false;
     int max_bounces = 512;
@@ -123,6 +124,7 @@ void pt_destroy(pt_ctx* c)
     for (hipEvent_t e : c->st_ev) if (e) (void)hipEventDestroy(e);
     if (c->d_env) (void)hipFree(c->d_env);
     if (c->d_cdf) (void)hipFree(c->d_cdf);
+    if (c->d_env_tables) (void)hipFree(c->d_env_tables);
     if (c->own_accum) (void)hipFree(c->own_accum);
     if (c->display) (void)hipFree(c->display);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
@@ -359,6 +361,12 @@ int pt_upload_envmap(pt_ctx* c, const float* rgba, const float* cdf, int w, int 
     HIP_TRY(hipMalloc((void**)&c->d_cdf, (size_t)w * h * sizeof(float)));
     HIP_TRY(hipMemcpy(c->d_env, rgba, (size_t)w * h * 4 * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->d_cdf, cdf, (size_t)w * h * sizeof(float), hipMemcpyHostToDevice));
+    if (c->d_env_tables) { (void)hipFree(c->d_env_tables); c->d_env_tables = nullptr; }
+    HIP_TRY(hipMalloc((void**)&c->d_env_tables, ((size_t)h + (size_t)w * h) * sizeof(float)));
+    launch_env_tables(c->d_cdf, w, h, c->d_env_tables, c->d_env_tables + h, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->scene.env_row_table = c->d_env_tables; c->scene.env_col_table = c->d_env_tables + h;
     c->scene.env_rgba = c->d_env; c->scene.env_cdf = c->d_cdf;
     c->scene.env_w = w; c->scene.env_h = h; c->scene.env_sum = sum;
     c->have_env = true;
@@ -455,7 +463,7 @@ static int wf_prepare(pt_ctx* c, int frames, WfParams* w)
     size_t slots = n_samples < (size_t)c->pool_slots ? n_samples : (size_t)c->pool_slots;
     slots = (slots + 255) / 256 * 256;
     size_t per_slot = 13 * sizeof(float4) + sizeof(uint32_t);
-    size_t need = slots * per_slot;
+    size_t need = slots * per_slot + (slots / 256) * sizeof(uint32_t) + (slots / 64) * 2 * sizeof(uint32_t);
     if (need > c->wf_block_bytes) {
         if (c->wf_block) { (void)hipFree(c->wf_block); c->wf_block = nullptr; c->wf_block_bytes = 0; }
         HIP_TRY(hipMalloc(&c->wf_block, need));
@@ -476,6 +484,8 @@ static int wf_prepare(pt_ctx* c, int frames, WfParams* w)
     float4** arrays[13] = {&w->ray_o, &w->ray_d, &w->hit, &w->c0, &w->c1, &w->c2, &w->d0, &w->d1, &w->e0, &w->e1, &w->e2, &w->e3, &w->e4};
     for (int i = 0; i < 13; i++) *arrays[i] = base + (size_t)i * slots;
     w->bsdf_queue = (uint32_t*)(base + (size_t)13 * slots);
+    w->bsdf_count = w->bsdf_queue + slots;
+    w->wave_chunk = w->bsdf_count + slots / 256;
     w->counters = c->wf_counters;
     w->staging = c->wf_staging;
     w->n_slots = (int)slots;

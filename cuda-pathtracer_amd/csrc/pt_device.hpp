@@ -635,7 +635,8 @@ PT_DEV F2 env_search(const DScene& S, float xi, uint32_t& taps_r)
     int lower = 0, upper = S.env_h - 1;
     while (lower < upper) {
         int mid = (lower + upper) >> 1;
-        float c = tex1(S.env_cdf, S.env_w, S.env_h, 1.f, (float)mid / (float)S.env_h);
+        // the value tex1(cdf, 1, mid/H) the reference looks up here, tabulated when the map was uploaded
+        float c = S.env_row_table[mid];
         if (COUNT) taps_r++;
         if (xi < c) upper = mid; else lower = mid + 1;
     }
@@ -643,7 +644,7 @@ PT_DEV F2 env_search(const DScene& S, float xi, uint32_t& taps_r)
     lower = 0; upper = S.env_w - 1;
     while (lower < upper) {
         int mid = (lower + upper) >> 1;
-        float c = tex1(S.env_cdf, S.env_w, S.env_h, (float)mid / (float)S.env_w, (float)y / (float)S.env_h);
+        float c = S.env_col_table[(size_t)y * S.env_w + mid];     // tex1(cdf, mid/W, y/H), tabulated
         if (COUNT) taps_r++;
         if (xi < c) upper = mid; else lower = mid + 1;
     }

@@ -134,6 +134,23 @@ void launch_resolve_display(const float* accum_dev, int n_pixels, int n_frames, 
     hipLaunchKernelGGL(resolve_display_kernel, grid, block, 0, stream, accum_dev, n_pixels, (float)n_frames, rgba_dev);
 }
 
+// ---------------------------------------------------------------- environment search tables
+// sampleEnvMap's binary searches (envmap_cuda.cu:28-57) compare against bilinearly filtered reads of
+// the CDF texture at fixed texel coordinates. Those reads depend only on the map, so they are
+// evaluated once here with the same sampler arithmetic; a search step then costs one load, not four.
+__global__ __launch_bounds__(256) void env_tables_kernel(const float* __restrict__ cdf, int w, int h, float* __restrict__ row_table, float* __restrict__ col_table)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= w * h) return;
+    int y = i / w, mid = i - y * w;
+    col_table[i] = tex1(cdf, w, h, (float)mid / (float)w, (float)y / (float)h);
+    if (mid == 0) row_table[y] = tex1(cdf, w, h, 1.f, (float)y / (float)h);
+}
+void launch_env_tables(const float* cdf_dev, int w, int h, float* row_table_dev, float* col_table_dev, hipStream_t stream)
+{
+    hipLaunchKernelGGL(env_tables_kernel, dim3((w * h + 255) / 256), dim3(256), 0, stream, cdf_dev, w, h, row_table_dev, col_table_dev);
+}
+
 // ---------------------------------------------------------------- numerics probe
 // Evaluates the pinned transcendentals on the device so tests can compare bits with the host.
 __global__ void detmath_probe_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, float* __restrict__ out)

@@ -43,6 +43,8 @@ struct DScene {
     const DTex* tex;
     const float* env_rgba;
     const float* env_cdf;
+    const float* env_row_table;   // [H]   filtered CDF lookups of the row search (envmap_cuda.cu:33)
+    const float* env_col_table;   // [H*W] filtered CDF lookups of the column search (envmap_cuda.cu:46)
     int env_w, env_h;
     float env_sum;
     int sky_mode;
@@ -73,7 +75,9 @@ struct WfParams {
     float4 *c0, *c1, *c2;           // (o, thr) (d, pdf) (result, flags, draws, sample id)
     float4 *d0, *d1;                // (transmittance, light pdf) (light radiance, bounce)
     float4 *e0, *e1, *e2, *e3, *e4; // vertex context: material values and shading normal
-    uint32_t* bsdf_queue;
+    uint32_t* bsdf_queue;           // [n_slots], one 256-entry segment per workgroup
+    uint32_t* bsdf_count;           // [n_slots/256] entries used in each segment
+    uint32_t* wave_chunk;           // [n_slots/64][2] next/end of the sample-id chunk each wave owns
     uint32_t* counters;
     float* staging;                 // n_frames * W * H sample values of the current chunk
     int n_slots;

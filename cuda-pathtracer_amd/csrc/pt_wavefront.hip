@@ -142,6 +142,37 @@ PT_DEV uint32_t wave_take(uint32_t* counter, bool need)
     return id;
 }
 
+// Sample ids are handed to the lanes of a wave from a chunk of 64 consecutive ids the wave owns (one
+// 8x8 tile of one frame when the image is tiled); the chunk cursor lives in global memory between
+// launches and a new chunk costs one atomic on the global counter. A single counter word serves only
+// about 90 returning atomics per microsecond chip-wide, far fewer than the waves of one launch.
+PT_DEV uint32_t take_samples(const WfParams& w, bool need)
+{
+    unsigned long long mask = __ballot(need);
+    if (mask == 0ull) return 0xFFFFFFFFu;
+    const int lane = (int)(threadIdx.x & 63u);
+    uint32_t* st = w.wave_chunk + 2 * ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
+    uint32_t next = st[0], end = st[1];
+    uint32_t n = (uint32_t)__popcll(mask);
+    uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    uint32_t avail = end - next;
+    uint32_t id;
+    if (n <= avail) {
+        id = next + rank;
+        next += n;
+    } else {
+        uint32_t c = 0;
+        if (lane == __ffsll((long long)mask) - 1) c = atomicAdd(w.counters + WF_CTR_NEXT_SAMPLE, 64u);
+        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)c, __ffsll((long long)mask) - 1, 64));
+        id = rank < avail ? next + rank : c + (rank - avail);
+        next = c + (n - avail);
+        end = c + 64u;
+        if (c >= w.n_samples) { next = w.n_samples; end = w.n_samples; }
+    }
+    if (lane == __ffsll((long long)mask) - 1) { st[0] = next; st[1] = end; }
+    return need ? id : 0xFFFFFFFFu;
+}
+
 // A finished sample: publish its value (pathtracer.cu:540,580: channel value * 3, clamped below at 0)
 // and start the next unstarted sample in this slot, if any.
 template <bool COUNT>
@@ -153,7 +184,7 @@ PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_
             float v = P.result * 3.f;
             w.staging[id.stage_index] = v > 0.f ? v : 0.f;
         }
-        uint32_t next = wave_take(w.counters + WF_CTR_NEXT_SAMPLE, finished);
+        uint32_t next = take_samples(w, finished);
         if (!__any(finished)) break;
         if (finished) {
             if (next < w.n_samples) {
@@ -207,9 +238,10 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
     uint32_t sample = 0xFFFFFFFFu;
     SampleId id = decode_sample(w, 0);
     uint32_t nsamples = 0;
+    if ((threadIdx.x & 63u) == 0) { uint32_t* st = w.wave_chunk + 2 * ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)); st[0] = 0; st[1] = 0; }
     // first fill: pretend every slot just finished a sample it never had (nothing is published)
     {
-        uint32_t next = wave_take(w.counters + WF_CTR_NEXT_SAMPLE, true);
+        uint32_t next = take_samples(w, true);
         bool finished = false;
         if (next < w.n_samples) {
             sample = next;
@@ -457,9 +489,20 @@ __global__ __launch_bounds__(kBlock) void wf_shade_kernel(WfParams w, DScene S, 
         finished = P.state == ST_DONE;
     }
     // slots that reached the bsdf stage: append to the queue
+    // compacted per workgroup (no global atomics): block b owns queue entries [b*256, b*256 + count[b])
     bool to_bsdf = live && P.state == ST_AFTER;
-    uint32_t qpos = wave_take(w.counters + WF_CTR_BSDF_COUNT, to_bsdf);
-    if (to_bsdf) w.bsdf_queue[qpos] = slot;
+    {
+        __shared__ uint32_t s_cnt[kBlock / 64];
+        unsigned long long qm = __ballot(to_bsdf);
+        const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+        if (lane == 0) s_cnt[wid] = (uint32_t)__popcll(qm);
+        __syncthreads();
+        uint32_t base = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < kBlock / 64; j++) { uint32_t cj = s_cnt[j]; if (j < wid) base += cj; total += cj; }
+        if (to_bsdf) w.bsdf_queue[(size_t)blockIdx.x * kBlock + base + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull))] = slot;
+        if (threadIdx.x == 0) w.bsdf_count[blockIdx.x] = total;
+    }
     if (__any(finished)) finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples);
     if (live) {
         if (P.state == ST_AFTER) {
@@ -472,8 +515,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade_kernel(WfParams w, DScene S, 
         store_light(w, slot, P);
     }
     bool alive = live && (P.state != ST_DONE);
-    unsigned long long m = __ballot(alive);
-    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(w.counters + WF_CTR_LIVE, (uint32_t)__popcll(m));
+    if (__any(alive) && (threadIdx.x & 63u) == 0) w.counters[WF_CTR_LIVE] = 1u;     // a flag, not a count: plain store
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
 
@@ -481,10 +523,10 @@ __global__ __launch_bounds__(kBlock) void wf_shade_kernel(WfParams w, DScene S, 
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_bsdf_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
+    uint32_t count = w.bsdf_count[blockIdx.x];
+    if ((threadIdx.x & ~63u) >= count) return;          // whole wave beyond this workgroup's queue
+    bool active = threadIdx.x < count;
     uint32_t q = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t count = w.counters[WF_CTR_BSDF_COUNT];
-    if ((q & ~63u) >= count) return;            // whole wave beyond the queue
-    bool active = q < count;
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
     Path P;
