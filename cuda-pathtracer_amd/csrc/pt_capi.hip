@@ -40,6 +40,7 @@ struct pt_ctx {
     pt_triangle* d_tri_ref = nullptr;
     DTri* d_tris = nullptr;
     DNode* d_nodes = nullptr;
+    DNodeQ* d_qnodes = nullptr;
     DMat* d_mats = nullptr;
     DTex* d_tex = nullptr;
     std::vector<DTex> tex_table;
@@ -56,9 +57,9 @@ struct pt_ctx {
     size_t n_nodes = 0;
     // wavefront pool
     int mode = PT_MODE_WAVEFRONT;
-    int pool_slots = 1 << 21;
+    int pool_slots = 1 << 23;
     int chunk_frames = 64;
-    int refill_lanes = 24, leaf_vote = 24, extend_blocks_per_cu = 5, n_cus = 256;
+    int refill_lanes = 8, leaf_vote = 12, extend_blocks_per_cu = 5, n_cus = 256;
     void* wf_block = nullptr;       // one allocation holding every slot array
     size_t wf_block_bytes = 0;
     float* wf_staging = nullptr;
@@ -108,6 +109,7 @@ static void free_scene_geometry(pt_ctx* c)
 {
     if (c->d_tris) { (void)hipFree(c->d_tris); c->d_tris = nullptr; }
     if (c->d_nodes) { (void)hipFree(c->d_nodes); c->d_nodes = nullptr; }
+    if (c->d_qnodes) { (void)hipFree(c->d_qnodes); c->d_qnodes = nullptr; }
     c->have_bvh = false;
 }
 
@@ -311,7 +313,35 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     }
     c->scene.root_min[0] = root.aabbMin.x; c->scene.root_min[1] = root.aabbMin.y; c->scene.root_min[2] = root.aabbMin.z;
     c->scene.root_max[0] = root.aabbMax.x; c->scene.root_max[1] = root.aabbMax.y; c->scene.root_max[2] = root.aabbMax.z;
+    // 16-bit grid over the (padded) root box for the compact nodes
+    std::vector<DNodeQ> qn(dn.size());
+    {
+        double org[3] = {root.aabbMin.x, root.aabbMin.y, root.aabbMin.z};
+        double ext[3] = {(double)root.aabbMax.x - root.aabbMin.x, (double)root.aabbMax.y - root.aabbMin.y, (double)root.aabbMax.z - root.aabbMin.z};
+        double cell[3];
+        for (int a = 0; a < 3; a++) {
+            if (!(ext[a] > 0.0)) ext[a] = 1.0;
+            cell[a] = ext[a] / 65531.0;           // cells 2..65533 span the box, two cells of slack on each side
+            c->scene.q_origin[a] = (float)(org[a] - 2.0 * cell[a]);
+            c->scene.q_cell[a] = (float)cell[a];
+            c->scene.q_inv_cell[a] = (float)(1.0 / cell[a]);
+        }
+        auto qlo = [&](float v, int a) { double q = std::floor(((double)v - (double)c->scene.q_origin[a]) / (double)c->scene.q_cell[a]) - 2.0; return (uint16_t)(q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q)); };
+        auto qhi = [&](float v, int a) { double q = std::ceil(((double)v - (double)c->scene.q_origin[a]) / (double)c->scene.q_cell[a]) + 2.0; return (uint16_t)(q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q)); };
+        for (size_t i = 0; i < dn.size(); i++) {
+            const DNode& s = dn[i];
+            DNodeQ& t = qn[i];
+            for (int a = 0; a < 3; a++) {
+                t.q[a] = qlo(s.lmin[a], a); t.q[3 + a] = qhi(s.lmax[a], a);
+                t.q[6 + a] = qlo(s.rmin[a], a); t.q[9 + a] = qhi(s.rmax[a], a);
+            }
+            t.left = s.left; t.right = s.right;
+        }
+    }
     free_scene_geometry(c);
+    HIP_TRY(hipMalloc((void**)&c->d_qnodes, qn.size() * sizeof(DNodeQ)));
+    HIP_TRY(hipMemcpy(c->d_qnodes, qn.data(), qn.size() * sizeof(DNodeQ), hipMemcpyHostToDevice));
+    c->scene.qnodes = c->d_qnodes;
     HIP_TRY(hipMalloc((void**)&c->d_nodes, dn.size() * sizeof(DNode)));
     HIP_TRY(hipMemcpy(c->d_nodes, dn.data(), dn.size() * sizeof(DNode), hipMemcpyHostToDevice));
     HIP_TRY(hipMalloc((void**)&c->d_tris, (dt.size() + 1) * sizeof(DTri)));
@@ -485,7 +515,7 @@ static int wf_prepare(pt_ctx* c, int frames, WfParams* w)
     for (int i = 0; i < 13; i++) *arrays[i] = base + (size_t)i * slots;
     w->bsdf_queue = (uint32_t*)(base + (size_t)13 * slots);
     w->bsdf_count = w->bsdf_queue + slots;
-    w->wave_chunk = w->bsdf_count + slots / 256;
+    w->block_chunk = w->bsdf_count + slots / 256;
     w->counters = c->wf_counters;
     w->staging = c->wf_staging;
     w->n_slots = (int)slots;
@@ -675,6 +705,57 @@ int pt_trace_closest_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* hits_
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     return PT_OK;
+}
+
+// Closest hits through the production traversal kernel (persistent waves, compact nodes): what the
+// wavefront renderer's extend stage runs. Device pointers.
+int pt_trace_closest_fast_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* hits_dev)
+{
+    int rc = check_ready(c, false);
+    if (rc != PT_OK) return rc;
+    if (n <= 0 || !rays_dev || !hits_dev) { set_error("pt_trace_closest_fast_dev: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    // borrow the pool's ray and hit arrays
+    size_t slots = ((size_t)n + 255) / 256 * 256;
+    size_t need = slots * (13 * sizeof(float4) + sizeof(uint32_t)) + (slots / 256) * sizeof(uint32_t) + (slots / 64) * 2 * sizeof(uint32_t);
+    if (need > c->wf_block_bytes) {
+        if (c->wf_block) { (void)hipFree(c->wf_block); c->wf_block = nullptr; c->wf_block_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->wf_block, need));
+        c->wf_block_bytes = need;
+    }
+    if (!c->wf_counters) {
+        HIP_TRY(hipMalloc((void**)&c->wf_counters, WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(c->wf_counters, 0, WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipHostMalloc((void**)&c->wf_host_counters, WF_CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    WfParams w{};
+    float4* base = (float4*)c->wf_block;
+    w.ray_o = base; w.ray_d = base + slots; w.hit = base + 2 * slots;
+    w.counters = c->wf_counters;
+    w.n_slots = n;
+    w.refill_lanes = c->refill_lanes; w.leaf_vote = c->leaf_vote; w.extend_blocks = c->extend_blocks_per_cu * c->n_cus;
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    launch_wf_trace(w, c->scene, rays_dev, n, hits_dev, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    return PT_OK;
+}
+
+int pt_trace_closest_fast(pt_ctx* c, const pt_ray* rays, int n, pt_hit* hits)
+{
+    if (!c || n <= 0 || !rays || !hits) { set_error("pt_trace_closest_fast: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    pt_ray* d_r = nullptr; pt_hit* d_h = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_r, (size_t)n * sizeof(pt_ray)));
+    HIP_TRY(hipMalloc((void**)&d_h, (size_t)n * sizeof(pt_hit)));
+    HIP_TRY(hipMemcpyAsync(d_r, rays, (size_t)n * sizeof(pt_ray), hipMemcpyHostToDevice, c->stream));
+    int rc = pt_trace_closest_fast_dev(c, d_r, n, d_h);
+    if (rc == PT_OK) {
+        HIP_TRY(hipMemcpyAsync(hits, d_h, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost, c->stream));
+        rc = pt_sync(c);
+    }
+    (void)hipFree(d_r); (void)hipFree(d_h);
+    return rc;
 }
 
 int pt_trace_closest_counted(pt_ctx* c, const pt_ray* rays, int n, pt_hit* hits, uint32_t* nbox, uint32_t* ntri)

@@ -18,6 +18,16 @@ struct __attribute__((aligned(64))) DNode {
 };
 static_assert(sizeof(DNode) == 64, "node must be one 64-byte record");
 
+// Compact interior node for the production traversal kernel, 32 bytes = two 16-byte loads. Child boxes
+// are stored as 16-bit grid coordinates over the scene box, rounded outward by two cells, so a box
+// here always contains the exact one; closest hits do not depend on which (conservative) boxes guide
+// the search, only the number of nodes visited does.
+struct __attribute__((aligned(32))) DNodeQ {
+    uint16_t q[12];       // lmin.xyz lmax.xyz rmin.xyz rmax.xyz
+    int left, right;      // as DNode
+};
+static_assert(sizeof(DNodeQ) == 32, "compact node must be 32 bytes");
+
 // Triangle record for intersection, 48 bytes = three 16-byte loads, stored in leaf order.
 // q0 = (a.xyz, original index), q1 = (b-a, triangles in this leaf [first record only]), q2 = (c-a, 0)
 struct __attribute__((aligned(16))) DTri { float4 q0, q1, q2; };
@@ -37,6 +47,8 @@ struct DTex { const float* texels; int w, h, comps, pad; };
 
 struct DScene {
     const DNode* nodes;
+    const DNodeQ* qnodes;         // same numbering as nodes
+    float q_origin[3], q_cell[3], q_inv_cell[3];
     const DTri* tris;             // leaf order
     const pt_triangle* tri_ref;   // original order, reference layout (shading attributes)
     const DMat* mats;
@@ -77,7 +89,7 @@ struct WfParams {
     float4 *e0, *e1, *e2, *e3, *e4; // vertex context: material values and shading normal
     uint32_t* bsdf_queue;           // [n_slots], one 256-entry segment per workgroup
     uint32_t* bsdf_count;           // [n_slots/256] entries used in each segment
-    uint32_t* wave_chunk;           // [n_slots/64][2] next/end of the sample-id chunk each wave owns
+    uint32_t* block_chunk;          // [n_slots/256][2] cursor/end of the sample-id chunk each workgroup owns
     uint32_t* counters;
     float* staging;                 // n_frames * W * H sample values of the current chunk
     int n_slots;

@@ -142,51 +142,63 @@ PT_DEV uint32_t wave_take(uint32_t* counter, bool need)
     return id;
 }
 
-// Sample ids are handed to the lanes of a wave from a chunk of 64 consecutive ids the wave owns (one
-// 8x8 tile of one frame when the image is tiled); the chunk cursor lives in global memory between
-// launches and a new chunk costs one atomic on the global counter. A single counter word serves only
-// about 90 returning atomics per microsecond chip-wide, far fewer than the waves of one launch.
-PT_DEV uint32_t take_samples(const WfParams& w, bool need)
-{
-    unsigned long long mask = __ballot(need);
-    if (mask == 0ull) return 0xFFFFFFFFu;
-    const int lane = (int)(threadIdx.x & 63u);
-    uint32_t* st = w.wave_chunk + 2 * ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6));
-    uint32_t next = st[0], end = st[1];
-    uint32_t n = (uint32_t)__popcll(mask);
-    uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    uint32_t avail = end - next;
-    uint32_t id;
-    if (n <= avail) {
-        id = next + rank;
-        next += n;
-    } else {
-        uint32_t c = 0;
-        if (lane == __ffsll((long long)mask) - 1) c = atomicAdd(w.counters + WF_CTR_NEXT_SAMPLE, 64u);
-        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)__shfl((int)c, __ffsll((long long)mask) - 1, 64));
-        id = rank < avail ? next + rank : c + (rank - avail);
-        next = c + (n - avail);
-        end = c + 64u;
-        if (c >= w.n_samples) { next = w.n_samples; end = w.n_samples; }
-    }
-    if (lane == __ffsll((long long)mask) - 1) { st[0] = next; st[1] = end; }
-    return need ? id : 0xFFFFFFFFu;
-}
+// Sample ids are handed out per workgroup from a chunk of kSampleChunk consecutive ids that the
+// workgroup owns (four 8x8 tiles of one frame when the image is tiled). The chunk cursor lives in
+// global memory between launches; a new chunk costs one atomic on the global counter, so a launch over
+// millions of slots issues a few thousand atomics instead of one per wave (a single counter word
+// serves only about 90 returning atomics per microsecond chip-wide). The chunk belongs to the
+// workgroup, not to a wave, because the bsdf stage runs a slot on whichever wave its queue position
+// falls to: every slot of a workgroup must draw from the same cursor, or ids left in one wave's chunk
+// would be stranded once that wave's own slots have retired.
+constexpr uint32_t kSampleChunk = 256;
 
 // A finished sample: publish its value (pathtracer.cu:540,580: channel value * 3, clamped below at 0)
-// and start the next unstarted sample in this slot, if any.
+// and start the next unstarted sample in this slot, if any. Must be called by every thread of the
+// workgroup (it synchronises).
 template <bool COUNT>
-PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_t slot, Path& P, uint32_t& sample, SampleId& id, bool finished, uint32_t& nsamples)
+PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_t slot, Path& P, uint32_t& sample, SampleId& id, bool finished, uint32_t& nsamples, bool first_fill)
 {
+    __shared__ uint32_t s_need[kBlock / 64];
+    __shared__ uint32_t s_plan[3];      // old cursor, ids available at the old cursor, base of the new chunk
+    __shared__ uint32_t s_chunk[2];     // cursor and end of the workgroup's chunk
+    const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    uint32_t* cw = w.block_chunk + 2 * (size_t)blockIdx.x;
+    if (threadIdx.x == 0) {
+        s_chunk[0] = first_fill ? 0u : cw[0];
+        s_chunk[1] = first_fill ? 0u : cw[1];
+    }
     // loops only while some fresh sample is born finished (its channel draw was exactly 1.0: 3e-8)
     for (;;) {
         if (finished) {
             float v = P.result * 3.f;
             w.staging[id.stage_index] = v > 0.f ? v : 0.f;
         }
-        uint32_t next = take_samples(w, finished);
-        if (!__any(finished)) break;
+        unsigned long long mask = __ballot(finished);
+        if (lane == 0) s_need[wid] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t total = 0, woff = 0;
+#pragma unroll
+        for (int j = 0; j < kBlock / 64; j++) { uint32_t nj = s_need[j]; if (j < wid) woff += nj; total += nj; }
+        if (total == 0) break;          // uniform over the workgroup
+        if (threadIdx.x == 0) {
+            uint32_t next = s_chunk[0], end = s_chunk[1];
+            uint32_t avail = end - next;
+            s_plan[0] = next;
+            if (total <= avail) {
+                s_plan[1] = total; s_plan[2] = 0;
+                next += total;
+            } else {
+                uint32_t c = atomicAdd(w.counters + WF_CTR_NEXT_SAMPLE, kSampleChunk);
+                s_plan[1] = avail; s_plan[2] = c;
+                next = c + (total - avail); end = c + kSampleChunk;
+                if (c >= w.n_samples) { next = w.n_samples; end = w.n_samples; }
+            }
+            s_chunk[0] = next; s_chunk[1] = end;
+        }
+        __syncthreads();
         if (finished) {
+            uint32_t r = woff + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            uint32_t next = r < s_plan[1] ? s_plan[0] + r : s_plan[2] + (r - s_plan[1]);
             if (next < w.n_samples) {
                 sample = next;
                 id = decode_sample(w, sample);
@@ -199,7 +211,35 @@ PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_
                 finished = false;
             }
         }
+        __syncthreads();                // s_need and s_plan are reused by the next round
     }
+    if (threadIdx.x == 0) { cw[0] = s_chunk[0]; cw[1] = s_chunk[1]; }
+}
+
+// First fill of the pool: like finish_and_regenerate with every slot "finished", except that there is
+// no previous sample to publish.
+template <bool COUNT>
+PT_DEV void first_fill_regenerate(const WfParams& w, const DCamera& cam, uint32_t slot, Path& P, uint32_t& sample, SampleId& id, uint32_t& nsamples)
+{
+    __shared__ uint32_t s_base;
+    // one chunk request for the whole workgroup: kBlock consecutive ids
+    if (threadIdx.x == 0) s_base = atomicAdd(w.counters + WF_CTR_NEXT_SAMPLE, (uint32_t)kBlock);
+    __syncthreads();
+    uint32_t next = s_base + threadIdx.x;
+    bool finished = false;
+    if (next < w.n_samples) {
+        sample = next;
+        id = decode_sample(w, sample);
+        begin_sample(P, cam, id.x, id.y, id.frame);
+        if (COUNT) nsamples++;
+        finished = P.state == ST_DONE;
+    } else {
+        P.state = ST_DONE;
+        sample = 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    // born-finished samples (and nothing else) go through the regular path; it also initialises the cursor
+    finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples, true);
 }
 
 template <bool COUNT>
@@ -229,8 +269,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera cam, DCounters* ctr)
 {
     uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    if (slot >= (uint32_t)w.n_slots) return;       // n_slots is a multiple of 64: whole waves leave together
-    Path P;
+    Path P;                                        // n_slots is a multiple of the workgroup size: no tail
     P.state = ST_DONE; P.result = 0.f; P.ch = 0; P.rng.draws = 0;
     P.inside = P.surface_scatter = P.sh_inside = P.nee_surface = P.nee_skip = P.v_inside = false;
     P.seg = 0; P.bounce = 0; P.thr = 1.f; P.pdf = 0.f;
@@ -238,20 +277,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
     uint32_t sample = 0xFFFFFFFFu;
     SampleId id = decode_sample(w, 0);
     uint32_t nsamples = 0;
-    if ((threadIdx.x & 63u) == 0) { uint32_t* st = w.wave_chunk + 2 * ((size_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6)); st[0] = 0; st[1] = 0; }
-    // first fill: pretend every slot just finished a sample it never had (nothing is published)
-    {
-        uint32_t next = take_samples(w, true);
-        bool finished = false;
-        if (next < w.n_samples) {
-            sample = next;
-            id = decode_sample(w, sample);
-            begin_sample(P, cam, id.x, id.y, id.frame);
-            if (COUNT) nsamples++;
-            finished = P.state == ST_DONE;
-        }
-        finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples);
-    }
+    first_fill_regenerate<COUNT>(w, cam, slot, P, sample, id, nsamples);
     store_ray(w, slot, P);
     store_core(w, slot, P, sample);
     store_light(w, slot, P);
@@ -282,6 +308,9 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
 #ifndef PT_SPLIT_NODE_LOAD
 #define PT_SPLIT_NODE_LOAD 0
 #endif
+#ifndef PT_QUANT_NODES
+#define PT_QUANT_NODES 1   // production traversal reads the 32-byte compact nodes
+#endif
 #ifndef PT_STAMPS
 #define PT_STAMPS 0      // diagnostic build: per-section cycle stamps in the extend kernel
 #endif
@@ -297,14 +326,21 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     __shared__ uint2 s_stack[kExtendLds * kBlock];
     uint2 spill[kSpillDepth];
     const int tid = (int)threadIdx.x;
+    const int lane = tid & 63;
     int cur = PT_TRAV_EMPTY, sp = 0;
     uint32_t slot = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = o, inv = o;
+    // ray in grid coordinates for the compact nodes (uncounted build only)
+    F3 oq = o, invq = o;
+    constexpr bool QUANT = !COUNT && PT_QUANT_NODES;
     Hit best; best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
     bool has_ray = false;
     bool more = true;
     uint32_t chunk_next = 0, chunk_end = 0;      // wave-uniform
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
+#if PT_STAMPS
+    unsigned long long st_iters = 0, st_lanes = 0, st_leafphases = 0, st_refills = 0, st_t0 = __builtin_amdgcn_s_memtime();
+#endif
 
     auto push = [&](int ref, float tn) {
         uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
@@ -330,83 +366,83 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         has_ray = false;
     };
 
-#if PT_STAMPS
-    unsigned long long st_refill = 0, st_load = 0, st_box = 0, st_leaf = 0, st_iters = 0, st_lanes = 0, st_leafphases = 0, st_t;
-#define STAMP(acc) do { unsigned long long n__ = __builtin_amdgcn_s_memtime(); acc += n__ - st_t; st_t = n__; } while (0)
-    st_t = __builtin_amdgcn_s_memtime();
-#else
-#define STAMP(acc) do { } while (0)
-#endif
     for (;;) {
-        bool idle = !has_ray;
-        int n_idle = __popcll(__ballot(idle));
-        if (more && n_idle >= w.refill_lanes) {
-            // rays are handed out from a wave-private chunk of consecutive slots; one global atomic per
-            // chunk (a single counter word serves only about 90 atomics per microsecond chip-wide)
+        // ---- decide what this pass does. Every lane is in exactly one state: idle, descending (cur is an
+        // interior node) or waiting at a leaf.
+        const bool idle = !has_ray;
+        const bool descending = has_ray && cur >= 0;
+        const bool at_leaf = has_ray && cur < 0;
+        const unsigned long long idle_mask = __ballot(idle);
+        const unsigned long long desc_mask = __ballot(descending);
+        const unsigned long long leaf_mask = __ballot(at_leaf);
+        const int n_idle = __popcll(idle_mask);
+        if (n_idle == 64 && !more) break;
+        const bool do_refill = more && n_idle >= w.refill_lanes;
+        const bool leaf_now = at_leaf && (__popcll(leaf_mask) >= w.leaf_vote || desc_mask == 0ull);
+#if PT_STAMPS
+        st_iters++; st_lanes += __popcll(desc_mask); st_leafphases += __any(leaf_now) ? 1 : 0; st_refills += do_refill ? 1 : 0;
+#endif
+        // ---- issue every load of the pass before anything waits: a pass then costs one memory latency,
+        // not one per kind of work
+        bool got = false;
+        uint32_t idx = 0;
+        float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4;
+        if (do_refill) {
+            // rays are handed out from a wave-private chunk of consecutive slots; one global atomic per chunk
             if (chunk_next >= chunk_end) {
                 uint32_t c = 0;
-                if ((tid & 63) == 0) c = atomicAdd(w.counters + WF_CTR_RAY_NEXT, (uint32_t)kRayChunk);
+                if (lane == 0) c = atomicAdd(w.counters + WF_CTR_RAY_NEXT, (uint32_t)kRayChunk);
                 c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
                 chunk_next = c;
                 chunk_end = c + kRayChunk < (uint32_t)w.n_slots ? c + kRayChunk : (uint32_t)w.n_slots;
                 if (c >= (uint32_t)w.n_slots) { more = false; chunk_end = chunk_next; }
             }
-            unsigned long long idle_mask = __ballot(idle);
-            uint32_t avail = chunk_end - chunk_next;
-            uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << (tid & 63)) - 1ull));
-            bool got = idle && rank < avail;
-            uint32_t idx = chunk_next + rank;
-            uint32_t taken = (uint32_t)__popcll(idle_mask);
-            chunk_next += taken < avail ? taken : avail;
-            if (got) {
-                float4 rd = w.ray_d[idx];
-                if (__float_as_int(rd.w) != 0) {
-                    float4 ro = w.ray_o[idx];
-                    slot = idx;
-                    o = f3(ro.x, ro.y, ro.z); d = f3(rd.x, rd.y, rd.z);
-                    best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
-                    sp = 0;
-                    has_ray = true;
-                    if (COUNT) tl.rays++;
-                    cur = PT_TRAV_EMPTY;
-                    if (finite3(o) && finite3(d)) {
-                        inv = 1.0f / d;
-                        if (COUNT) tl.box += 1;
-                        float troot = box_entry(o, inv, S.root_min, S.root_max);
-                        if (troot < best.t) cur = S.root_ref;
-                    }
-                    if (cur == PT_TRAV_EMPTY) retire();
-                }
+            const uint32_t avail = chunk_end - chunk_next;
+            const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
+            got = idle && rank < avail;
+            idx = chunk_next + rank;
+            chunk_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
+            if (got) { rd4 = w.ray_d[idx]; ro4 = w.ray_o[idx]; }
+        }
+        float4 n0 = ro4, n1 = ro4, n2 = ro4, n3 = ro4;
+        if (descending) {
+            if (QUANT) {
+                const float4* np = reinterpret_cast<const float4*>(S.qnodes + cur);
+                n0 = np[0]; n1 = np[1];
+            } else {
+                const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
+                n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
             }
-            n_idle = __popcll(__ballot(!has_ray));
         }
-        if (n_idle == 64 || (!more && !__any(has_ray))) {
-            if (!more) break;
-            continue;
+        float4 q0 = ro4, q1 = ro4, q2 = ro4;
+        const DTri* tp = S.tris;
+        if (leaf_now) {
+            tp = S.tris + (~cur);
+            q0 = tp[0].q0; q1 = tp[0].q1; q2 = tp[0].q2;
         }
-        STAMP(st_refill);
-#if PT_STAMPS
-        st_iters++; st_lanes += __popcll(__ballot(has_ray && cur >= 0));
-#endif
+        asm volatile("" ::: "memory");      // loads stay above, their uses below
+
         // ---- one interior step for every descending lane
-        if (has_ray && cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(S.nodes + cur);
-            float4 n0 = np[0];
-#if PT_SPLIT_NODE_LOAD
-            // The four 16-byte loads of a node go to one cache line. Issued back to back, the last three
-            // queue in the L1 behind the miss of the first and stall its pipeline for every wave of the
-            // CU; waiting for the first makes them plain hits.
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(n0.x), "+v"(n0.y), "+v"(n0.z), "+v"(n0.w) :: "memory");
-#endif
-            float4 n1 = np[1], n2 = np[2], n3 = np[3];
-#if PT_STAMPS
-            asm volatile("s_waitcnt vmcnt(0)" : "+v"(n1.x), "+v"(n2.x), "+v"(n3.x), "+v"(n3.y) :: "memory");
-#endif
-            float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
-            float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
-            int left = __float_as_int(n3.x), right = __float_as_int(n3.y);
-            float dl = box_entry(o, inv, lmin, lmax);
-            float dr = box_entry(o, inv, rmin, rmax);
+        if (descending) {
+            int left, right;
+            float dl, dr;
+            if (QUANT) {
+                uint32_t w0 = __float_as_uint(n0.x), w1 = __float_as_uint(n0.y), w2 = __float_as_uint(n0.z), w3 = __float_as_uint(n0.w);
+                uint32_t w4 = __float_as_uint(n1.x), w5 = __float_as_uint(n1.y);
+                float lmin[3] = {(float)(w0 & 0xffffu), (float)(w0 >> 16), (float)(w1 & 0xffffu)};
+                float lmax[3] = {(float)(w1 >> 16), (float)(w2 & 0xffffu), (float)(w2 >> 16)};
+                float rmin[3] = {(float)(w3 & 0xffffu), (float)(w3 >> 16), (float)(w4 & 0xffffu)};
+                float rmax[3] = {(float)(w4 >> 16), (float)(w5 & 0xffffu), (float)(w5 >> 16)};
+                left = __float_as_int(n1.z); right = __float_as_int(n1.w);
+                dl = box_entry(oq, invq, lmin, lmax);
+                dr = box_entry(oq, invq, rmin, rmax);
+            } else {
+                float lmin[3] = {n0.x, n0.y, n0.z}, lmax[3] = {n0.w, n1.x, n1.y};
+                float rmin[3] = {n1.z, n1.w, n2.x}, rmax[3] = {n2.y, n2.z, n2.w};
+                left = __float_as_int(n3.x); right = __float_as_int(n3.y);
+                dl = box_entry(o, inv, lmin, lmax);
+                dr = box_entry(o, inv, rmin, rmax);
+            }
             if (COUNT) tl.box += 2;
             int nearR, farR; float dn, df;
             if (dl > dr) { nearR = right; dn = dr; farR = left; df = dl; }
@@ -415,41 +451,49 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
             if (dn < best.t) cur = nearR;
             else { cur = pop_valid(); if (cur == PT_TRAV_EMPTY) retire(); }
         }
-#if PT_STAMPS
-        {   // split the interior step into "until the node arrived" and "the rest": re-stamp is approximate (whole step here)
-            STAMP(st_box);
-        }
-#endif
-        // ---- leaf work, once enough lanes wait at a leaf or nobody can descend
-        bool at_leaf = has_ray && cur < 0;
-        unsigned long long leaf_mask = __ballot(at_leaf);
-        if (leaf_mask != 0ull && (__popcll(leaf_mask) >= w.leaf_vote || !__any(has_ray && cur >= 0))) {
-            if (at_leaf) {
-                const DTri* tp = S.tris + (~cur);
-                int count = 1;
-                for (int i = 0; i < count; i++) {
-                    float4 q0 = tp[i].q0, q1 = tp[i].q1, q2 = tp[i].q2;
-                    if (i == 0) count = __float_as_int(q1.w);
-                    uint32_t id = __float_as_uint(q0.w);
-                    float t, u, v;
-                    if (COUNT) tl.tri += 1;
-                    if (!tri_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), o, d, best.t, t, u, v)) continue;
-                    if (best.tri != PT_NO_TRI && t == best.t && id > best.tri) continue;
+        // ---- leaf work for the lanes that waited at a leaf
+        if (leaf_now) {
+            int count = __float_as_int(q1.w);
+            for (int i = 0;;) {
+                uint32_t id = __float_as_uint(q0.w);
+                float t, u, v;
+                if (COUNT) tl.tri += 1;
+                if (tri_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), o, d, best.t, t, u, v) &&
+                    !(best.tri != PT_NO_TRI && t == best.t && id > best.tri)) {
                     best.t = t; best.tri = id; best.u = u; best.v = v;
                 }
-                cur = pop_valid();
-                if (cur == PT_TRAV_EMPTY) retire();
+                if (++i >= count) break;
+                q0 = tp[i].q0; q1 = tp[i].q1; q2 = tp[i].q2;
             }
-#if PT_STAMPS
-            st_leafphases++;
-#endif
+            cur = pop_valid();
+            if (cur == PT_TRAV_EMPTY) retire();
         }
-        STAMP(st_leaf);
+        // ---- new rays for the lanes that were idle
+        if (got && __float_as_int(rd4.w) != 0) {
+            slot = idx;
+            o = f3(ro4.x, ro4.y, ro4.z); d = f3(rd4.x, rd4.y, rd4.z);
+            best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
+            sp = 0;
+            has_ray = true;
+            if (COUNT) tl.rays++;
+            cur = PT_TRAV_EMPTY;
+            if (finite3(o) && finite3(d)) {
+                inv = 1.0f / d;
+                if (COUNT) tl.box += 1;
+                float troot = box_entry(o, inv, S.root_min, S.root_max);
+                if (troot < best.t) cur = S.root_ref;
+                if (QUANT) {
+                    oq = (o - ld3(S.q_origin)) * ld3(S.q_inv_cell);
+                    invq = inv * ld3(S.q_cell);
+                }
+            }
+            if (cur == PT_TRAV_EMPTY) retire();
+        }
     }
 #if PT_STAMPS
-    if ((threadIdx.x & 63) == 0) {
+    if (lane == 0) {
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(w.counters + WF_CTR_WORDS);
-        atomicAdd(dbg + 0, st_refill); atomicAdd(dbg + 1, st_box); atomicAdd(dbg + 2, st_leaf); atomicAdd(dbg + 3, st_iters);
+        atomicAdd(dbg + 0, __builtin_amdgcn_s_memtime() - st_t0); atomicAdd(dbg + 1, st_refills); atomicAdd(dbg + 3, st_iters);
         atomicAdd(dbg + 4, st_lanes); atomicAdd(dbg + 5, st_leafphases); atomicAdd(dbg + 6, 1ull);
     }
 #endif
@@ -503,7 +547,7 @@ __global__ __launch_bounds__(kBlock) void wf_shade_kernel(WfParams w, DScene S, 
         if (to_bsdf) w.bsdf_queue[(size_t)blockIdx.x * kBlock + base + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull))] = slot;
         if (threadIdx.x == 0) w.bsdf_count[blockIdx.x] = total;
     }
-    if (__any(finished)) finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples);
+    finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples, false);
     if (live) {
         if (P.state == ST_AFTER) {
             // the bsdf stage reads the shadow direction from the ray arrays; mark the slot as having no ray to trace
@@ -524,7 +568,7 @@ template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_bsdf_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
     uint32_t count = w.bsdf_count[blockIdx.x];
-    if ((threadIdx.x & ~63u) >= count) return;          // whole wave beyond this workgroup's queue
+    if (count == 0) return;                              // uniform over the workgroup
     bool active = threadIdx.x < count;
     uint32_t q = blockIdx.x * kBlock + threadIdx.x;
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
@@ -544,7 +588,7 @@ __global__ __launch_bounds__(kBlock) void wf_bsdf_kernel(WfParams w, DScene S, D
         after_light<COUNT>(S, cam, P, tl);
         finished = P.state == ST_DONE;
     }
-    if (__any(finished)) finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples);
+    finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples, false);
     if (active) {
         store_ray(w, slot, P);
         store_core(w, slot, P, sample);
@@ -574,7 +618,7 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate_kernel(WfParams w, DCame
     accum[3 * (size_t)p] = acc.x; accum[3 * (size_t)p + 1] = acc.y; accum[3 * (size_t)p + 2] = acc.z;
 }
 
-// ---------------------------------------------------------------- launchers
+// ---------------------------------------------------------------- closest-hit batch through the production traversal
 __global__ void wf_reset_iteration_kernel(uint32_t* counters)
 {
     counters[WF_CTR_LIVE_PREV] = counters[WF_CTR_LIVE];
@@ -583,6 +627,34 @@ __global__ void wf_reset_iteration_kernel(uint32_t* counters)
     counters[WF_CTR_RAY_NEXT] = 0;
 }
 
+__global__ __launch_bounds__(kBlock) void wf_pack_rays_kernel(const pt_ray* __restrict__ rays, int n, float4* __restrict__ ray_o, float4* __restrict__ ray_d)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4* r = reinterpret_cast<const float4*>(rays + i);
+    float4 o = r[0], d = r[1];
+    ray_o[i] = make_float4(o.x, o.y, o.z, 0.f);
+    ray_d[i] = make_float4(d.x, d.y, d.z, __int_as_float(1));
+}
+__global__ __launch_bounds__(kBlock) void wf_unpack_hits_kernel(const float4* __restrict__ hit, int n, pt_hit* __restrict__ out)
+{
+    int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float4 h = hit[i];
+    pt_hit o; o.t = h.x; o.tri = __float_as_uint(h.y);
+    out[i] = o;
+}
+void launch_wf_trace(const WfParams& w, const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, hipStream_t s)
+{
+    dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
+    hipLaunchKernelGGL(wf_pack_rays_kernel, grid, block, 0, s, rays_dev, n, w.ray_o, w.ray_d);
+    hipLaunchKernelGGL(wf_reset_iteration_kernel, dim3(1), dim3(1), 0, s, w.counters);
+    int ext_blocks = (int)grid.x < w.extend_blocks ? (int)grid.x : w.extend_blocks;
+    hipLaunchKernelGGL(wf_extend_kernel<false>, dim3(ext_blocks), block, 0, s, w, S, (DCounters*)nullptr);
+    hipLaunchKernelGGL(wf_unpack_hits_kernel, grid, block, 0, s, w.hit, n, hits_dev);
+}
+
+// ---------------------------------------------------------------- launchers
 void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, hipStream_t s)
 {
     dim3 grid((w.n_slots + kBlock - 1) / kBlock), block(kBlock);

@@ -21,7 +21,7 @@ EXPORTS = [
     'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_upload_texture', 'pt_upload_envmap',
     'pt_set_sky_mode', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_extend_tuning', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
     'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_trace_closest', 'pt_trace_closest_dev',
-    'pt_trace_closest_counted', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
+    'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
     'pt_detmath_probe', 'pt_read_obj', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
     'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
     'pt_host_build_bvh', 'pt_load_hdr', 'pt_build_env_cdf', 'pt_free', 'pt_camera_basis',
@@ -256,6 +256,12 @@ class Renderer:
             check(lib().pt_trace_closest_counted(self.h, _p(rays), C.c_int(len(rays)), _p(hits), _p(nb), _p(nt)))
             return hits, nb, nt
         check(lib().pt_trace_closest(self.h, _p(rays), C.c_int(len(rays)), _p(hits)))
+        return hits
+
+    def trace_closest_fast(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(len(rays), dtype=HIT_DTYPE)
+        check(lib().pt_trace_closest_fast(self.h, _p(rays), C.c_int(len(rays)), _p(hits)))
         return hits
 
     def trace_closest_dev(self, rays_ptr, n, hits_ptr):

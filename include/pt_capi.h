@@ -172,6 +172,8 @@ int pt_save_png(const char* path, const uint8_t* rgba, int w, int h);   /* saveT
 /* ---- closest-hit batch (test and measurement entry) ---- */
 int pt_trace_closest(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hits_out);
 int pt_trace_closest_dev(pt_ctx* ctx, const pt_ray* rays_dev, int n, pt_hit* hits_dev);
+int pt_trace_closest_fast(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hits_out);      /* same results through the traversal kernel the renderer uses (persistent waves, compact nodes) */
+int pt_trace_closest_fast_dev(pt_ctx* ctx, const pt_ray* rays_dev, int n, pt_hit* hits_dev);
 int pt_trace_closest_counted(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hits_out, uint32_t* box_tests_out, uint32_t* tri_tests_out);
 
 int pt_get_counters(pt_ctx* ctx, pt_counters* out);

@@ -7,12 +7,14 @@ from ptamd import scenes, lib
 b = util.atrium()
 P = scenes.atrium_params(ptamd.default_params(1920, 1080))
 r = b.renderer(P)
+pool = int(os.environ.get('POOL', '2097152')); tune = [int(x) for x in os.environ.get('TUNE', '24,24,5').split(',')]
+r.set_pool(pool, 64); r.set_extend_tuning(*tune)
+print('pool', pool, 'tune', tune)
 r.render(P, 0, 4)
 d = (C.c_ulonglong * 16)()
 lib.check(lib.lib().pt_debug_words(r.h, d))
 r.render(P, 4, 20)
 lib.check(lib.lib().pt_debug_words(r.h, d))
-refill, box, leaf, iters, lanes, leafph, waves = [d[i] for i in range(7)]
-tot = refill + box + leaf
-print('waves %d  iterations/wave %.0f  cycles/iteration %.0f  (refill+vote %.0f, interior step %.0f, leaf phase %.0f)' % (waves, iters / waves, tot / iters, refill / iters, box / iters, leaf / iters))
-print('descending lanes per iteration %.1f   leaf phases per iteration %.3f' % (lanes / iters, leafph / iters))
+total, refills, _, iters, lanes, leafph, waves = [d[i] for i in range(7)]
+print('waves %d  iterations/wave %.0f  cycles/iteration %.0f  descending lanes/iteration %.1f  leaf passes/iteration %.3f  refills/iteration %.3f'
+      % (waves, iters / waves, total / iters, lanes / iters, leafph / iters, refills / iters))
