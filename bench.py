@@ -46,7 +46,7 @@ def main():
     ap.add_argument('--bounces', type=int, default=512)
     ap.add_argument('--detail', type=float, default=None, help='atrium tessellation (default: about 262k triangles)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU oracle baseline')
-    ap.add_argument('--cpu-spp', type=int, default=1)
+    ap.add_argument('--cpu-spp', type=int, default=12, help='frames the CPU oracle renders for the baseline (about 15 s on 16 cores)')
     ap.add_argument('--mode', choices=['wavefront', 'single_kernel'], default='wavefront')
     ap.add_argument('--pool', type=int, default=0, help='wavefront pool slots (0 = library default)')
     ap.add_argument('--tune', type=str, default='', help='refill_lanes,leaf_vote,blocks_per_cu for the traversal kernel')
