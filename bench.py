@@ -96,11 +96,10 @@ def main():
     kernel_ms = []
 
     def step(k, timed):
-        f0 = (k * world + rank) * spp
+        f0, f1 = ptamd.partition.step_frames(k, world, rank, spp)
         accum.zero_()
-        r.render(P, f0, f0 + spp, sync=False)
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+        r.render(P, f0, f1, sync=False)
+        ptamd.partition.reduce_accum(accum, dst=0)
         if rank == 0:
             r.resolve_display(spp * world)
         else:
@@ -128,8 +127,8 @@ def main():
     r.enable_counters(True)
     r.reset_counters()
     for k in range(args.steps):
-        f0 = ((args.warmup + k) * world + rank) * spp
-        r.render(P, f0, f0 + spp)
+        f0, f1 = ptamd.partition.step_frames(args.warmup + k, world, rank, spp)
+        r.render(P, f0, f1)
     c = r.counters()
     r.enable_counters(False)
     keys = ['rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps', 'tex_taps_r']

@@ -134,6 +134,20 @@ typedef struct pt_counters {
     double   last_ms;       /* device time of the last render / trace call (HIP events) */
 } pt_counters;
 
+/* The PODs are binary-compatible with the reference's structs as nvcc lays them out (structs.cuh:111-181). */
+#ifdef __cplusplus
+#define PT_SIZE_CHECK(T, N) static_assert(sizeof(T) == N, #T " must be " #N " bytes")
+#else
+#define PT_SIZE_CHECK(T, N) _Static_assert(sizeof(T) == N, #T " must be " #N " bytes")
+#endif
+PT_SIZE_CHECK(pt_triangle, 112);
+PT_SIZE_CHECK(pt_bvh_node, 32);
+PT_SIZE_CHECK(pt_material, 176);
+PT_SIZE_CHECK(pt_params, 152);
+PT_SIZE_CHECK(pt_ray, 32);
+PT_SIZE_CHECK(pt_hit, 8);
+#undef PT_SIZE_CHECK
+
 typedef struct pt_ctx pt_ctx;
 
 const char* pt_last_error(void);

@@ -207,3 +207,45 @@ def detmath_probe(x, y):
     out = np.zeros((len(x), 12), dtype=np.float32)
     lib().orc_detmath_probe(_p(x), _p(y), C.c_int(len(x)), _p(out))
     return out
+
+
+def _f3(v):
+    return (C.c_float * 3)(*[float(x) for x in v])
+
+
+def bsdf_eval(mat, inside, V, N, L):
+    """DisneyEval_2 (disney.cuh:234-353) on one material record: returns (f[3], pdf)."""
+    m = np.ascontiguousarray(mat, dtype=MAT_DTYPE).reshape(1)
+    f = (C.c_float * 3)()
+    pdf = C.c_float()
+    lib().orc_bsdf_eval(_p(m), C.c_int(int(inside)), _f3(V), _f3(N), _f3(L), f, C.byref(pdf))
+    return np.array(list(f), np.float32), pdf.value
+
+
+def bsdf_sample(mat, inside, V, N, pixel, frame):
+    """DisneySample_2 (disney.cuh:355-460) with the random stream of (pixel, frame): returns (L, f, pdf, inside')."""
+    m = np.ascontiguousarray(mat, dtype=MAT_DTYPE).reshape(1)
+    L, f = (C.c_float * 3)(), (C.c_float * 3)()
+    pdf, ins = C.c_float(), C.c_int()
+    lib().orc_bsdf_sample(_p(m), C.c_int(int(inside)), _f3(V), _f3(N), C.c_uint32(pixel), C.c_int(frame), L, f, C.byref(pdf), C.byref(ins))
+    return np.array(list(L), np.float32), np.array(list(f), np.float32), pdf.value, bool(ins.value)
+
+
+def env_eval(scene, d):
+    out = (C.c_float * 4)()
+    cs = scene.c_scene()
+    lib().orc_env_eval(C.byref(cs), _f3(d), out)
+    return np.array(list(out), np.float32)
+
+
+def env_sample(scene, pixel, frame):
+    dp, col = (C.c_float * 4)(), (C.c_float * 3)()
+    cs = scene.c_scene()
+    lib().orc_env_sample(C.byref(cs), C.c_uint32(pixel), C.c_int(frame), dp, col)
+    return np.array(list(dp), np.float32), np.array(list(col), np.float32)
+
+
+def sky_gradient(d, sun):
+    out = (C.c_float * 3)()
+    lib().orc_sky_gradient(_f3(d), _f3(sun), out)
+    return np.array(list(out), np.float32)

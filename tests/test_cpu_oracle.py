@@ -1,0 +1,417 @@
+"""CPU tests (no GPU): the oracle against published known-answer vectors, hand-derived values, its own
+exhaustive variants and the committed golden fixtures."""
+import os
+import math
+import numpy as np
+import pytest
+
+import ptamd
+from ptamd import scenes, lib
+from ptamd.types import RAY_DTYPE
+import orc
+import util
+from util import bits
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+# ------------------------------------------------------------------ random numbers
+# Random123 kat_vectors, philox4x32 with 10 rounds (counter, key, expected)
+PHILOX_KAT = [
+    ((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+    ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+    ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)),
+]
+
+
+@pytest.mark.parametrize('ctr,key,want', PHILOX_KAT)
+def test_philox4x32_10_known_answers(ctr, key, want):
+    assert tuple(orc.philox(ctr, key)) == want
+
+
+def test_uniform_stream_follows_curand_init_semantics():
+    """curand_init(pixel, 0, 4096*frame) (pathtracer.cu:560): key = (pixel, 0), the frame skips 4096 draws of
+    the same sequence; a draw is x * 2^-32 + 2^-33, so it lies in (0, 1]."""
+    pixel = 12345
+    long = orc.uniform_stream(pixel, 0, 4096 + 16)
+    assert np.array_equal(orc.uniform_stream(pixel, 1, 16), long[4096:])
+    words = orc.philox((0, 0, 0, 0), (pixel, 0))
+    want = np.array([np.float32(w * 2.0 ** -32 + 2.0 ** -33) for w in words], np.float32)
+    assert np.array_equal(long[:4], want)
+    words = orc.philox((1024 * 3 + 1, 0, 0, 0), (pixel, 0))
+    want = np.array([np.float32(w * 2.0 ** -32 + 2.0 ** -33) for w in words], np.float32)
+    assert np.array_equal(orc.uniform_stream(pixel, 3, 8)[4:], want)
+    u = orc.uniform_stream(7, 2, 100000)
+    assert u.min() > 0.0 and u.max() <= 1.0
+    assert abs(float(u.mean()) - 0.5) < 0.005
+    assert not np.array_equal(orc.uniform_stream(8, 2, 16), u[:16])
+
+
+# ------------------------------------------------------------------ pinned transcendentals
+def ulp_err(got, want64):
+    want = want64.astype(np.float32)
+    ok = np.isfinite(want) & np.isfinite(got) & (np.abs(want64) > 1e-30) & (np.abs(want64) < 3e38)
+    spacing = np.spacing(np.abs(want[ok]))
+    return float(np.max(np.abs(got[ok].astype(np.float64) - want64[ok]) / spacing)) if ok.any() else 0.0
+
+
+def test_pinned_transcendentals_are_accurate():
+    """The arithmetic both sides share must be a faithful libm replacement (within 1 ulp of the exact value)."""
+    rng = np.random.default_rng(11)
+    n = 200000
+    x = np.concatenate([rng.uniform(-20, 20, n // 2), np.exp(rng.uniform(-30, 30, n // 4)), rng.uniform(-1, 1, n // 4)]).astype(np.float32)
+    y = np.concatenate([rng.uniform(-4, 4, n // 2), rng.uniform(-2, 2, n // 2)]).astype(np.float32)
+    out = orc.detmath_probe(x, y)
+    xd, yd = x.astype(np.float64), y.astype(np.float64)
+    with np.errstate(all='ignore'):
+        small = np.abs(x) < 1e4           # the path uses |x| <= 2 pi; the reduction loses relative accuracy near zeros of huge arguments
+        assert ulp_err(out[small, 0], np.sin(xd[small])) <= 1.0
+        assert ulp_err(out[small, 1], np.cos(xd[small])) <= 1.0
+        assert ulp_err(out[:, 2], np.exp(xd)) <= 1.0
+        pos = x > 0
+        assert ulp_err(out[pos, 3], np.log(xd[pos])) <= 1.0
+        assert ulp_err(out[pos, 4], np.log2(xd[pos])) <= 1.0
+        assert ulp_err(out[pos, 5], np.power(xd[pos], yd[pos])) <= 1.0
+        inside = np.abs(x) <= 1
+        assert ulp_err(out[inside, 6], np.arccos(xd[inside])) <= 1.0
+        assert ulp_err(out[:, 7], np.arctan2(xd, yd)) <= 1.0
+        assert np.array_equal(bits(out[:, 8]), bits((np.float32(1) / x)))
+        assert np.array_equal(bits(out[pos, 9]), bits(np.sqrt(x[pos])))
+    special = orc.detmath_probe(np.array([0.0, 1.0, np.inf, -1.0], np.float32), np.array([1.0, 0.0, 1.0, -0.0], np.float32))
+    assert special[0, 0] == 0 and special[0, 1] == 1 and special[0, 2] == 1
+    assert special[1, 3] == 0 and special[1, 4] == 0 and special[1, 5] == 1
+    assert special[1, 6] == 0 and abs(special[3, 6] - math.pi) < 1e-6
+    assert special[2, 2] == np.inf
+
+
+# ------------------------------------------------------------------ closest hit
+@pytest.mark.parametrize('n_tri', [1, 2, 7, 300, 5000])
+def test_bvh_traversal_equals_exhaustive_search(n_tri):
+    extent = 40.0 + n_tri ** (1 / 3) * 6
+    b = util.soup(n_tri, seed=100 + n_tri, extent=extent, edge=8.0)
+    rays = scenes.random_rays(4000, seed=4, extent=extent * 1.1)
+    S = b.oracle()
+    brute = orc.closest_brute(S, rays)
+    got = orc.closest_bvh(S, rays)
+    ref_order = orc.closest_reference_order(S, rays)
+    assert np.array_equal(got['tri'], brute['tri']) and np.array_equal(bits(got['t']), bits(brute['t']))
+    # the reference's own traversal keeps the last of equal-t candidates; t itself must agree
+    assert np.array_equal(bits(ref_order['t']), bits(brute['t']))
+    if n_tri >= 300:
+        assert (brute['tri'] != 0xFFFFFFFF).sum() > 0
+    miss = brute['tri'] == 0xFFFFFFFF
+    assert np.all(brute['t'][miss] == np.float32(1e10))
+
+
+def test_triangle_test_edge_rules():
+    """triangleIntersect (pathtracer.cu:124-141): |det| < 1e-4 rejected, u in [0,1], v >= 0, u+v <= 1, t >= 0;
+    hits exactly on an edge or a vertex count; duplicates resolve to the lowest index."""
+    tris = np.zeros(3, dtype=ptamd.TRI_DTYPE)
+    tris['a'] = [[0, 0, 0], [0, 0, 0], [0, 0, 5]]
+    tris['b'] = [[10, 0, 0], [10, 0, 0], [10, 0, 5]]
+    tris['c'] = [[0, 10, 0], [0, 10, 0], [0, 10, 5]]
+    S = orc.Scene(tris, ptamd.default_materials(1))
+    rays = np.zeros(7, dtype=RAY_DTYPE)
+    rays['d'] = [0, 0, -1]
+    rays['o'] = [[2, 2, 10], [0, 0, 10], [5, 5, 10], [10, 0, 10], [5.001, 5.001, 10], [-0.001, 3, 10], [2, 2, -1]]
+    h = orc.closest_brute(S, rays)
+    assert list(h['tri'][:4]) == [2, 2, 2, 2] and np.all(h['t'][:4] == 5.0)
+    assert h['tri'][4] == 0xFFFFFFFF and h['tri'][5] == 0xFFFFFFFF
+    assert h['tri'][6] == 0xFFFFFFFF          # behind the origin (t < 0)
+    rays['o'][:, 2] = 4.0                      # between the planes: only the two coincident triangles remain
+    h = orc.closest_brute(S, rays[:4])
+    assert list(h['tri']) == [0, 0, 0, 0] and np.all(h['t'] == 4.0)
+    # grazing ray: determinant below the threshold
+    g = np.zeros(1, dtype=RAY_DTYPE)
+    g['o'] = [-5, 2, 0]; g['d'] = [1, 0, 0]
+    assert orc.closest_brute(S, g)['tri'][0] == 0xFFFFFFFF
+
+
+# ------------------------------------------------------------------ BVH builder
+def _tree_stats(nodes):
+    depth = np.zeros(len(nodes), np.int32)
+    leaves, maxd = 0, 0
+    stack = [(0, 0)]
+    while stack:
+        i, d = stack.pop()
+        maxd = max(maxd, d)
+        if nodes['triCount'][i] > 0:
+            leaves += 1
+        else:
+            stack.append((int(nodes['leftFirst'][i]), d + 1))
+            stack.append((int(nodes['leftFirst'][i]) + 1, d + 1))
+    return leaves, maxd
+
+
+def _bunny_scene(tmp_path):
+    import shutil
+    d = str(tmp_path)
+    shutil.copy(os.path.join(GOLDEN, 'bunny_triangle_2.obj.txt'), os.path.join(d, 'Bunny_triangle_2.txt'))
+    with open(os.path.join(d, 'Bunny_triangle_2.mtl'), 'w') as f:
+        f.write('newmtl none\n')
+    return ptamd.HostScene(os.path.join(d, 'Bunny_triangle_2.txt'), d + '/')
+
+
+def test_reference_builder_on_the_shipped_bunny(tmp_path):
+    """The one mesh the reference ships (assets/models/Bunny_triangle_2.txt): the reference's own builder,
+    compiled for the host, gives 583 nodes, one triangle in every leaf, depth 11."""
+    hs = _bunny_scene(tmp_path)
+    assert len(hs.tris) == 292
+    S = orc.Scene(hs.tris, hs.mats)
+    used = S.build_bvh_reference()
+    assert used == 583
+    nodes = S.nodes[:used]
+    leaves, depth = _tree_stats(nodes)
+    assert leaves == 292 and depth == 11
+    assert np.all(nodes['triCount'][nodes['triCount'] > 0] == 1)
+    assert sorted(S.tri_idx.tolist()) == list(range(292))
+    # centroid rule BVH_builder.cpp:119: (a + b + c) * 0.3333f
+    want = (S.tris['a'] + S.tris['b'] + S.tris['c']) * np.float32(0.3333)
+    assert np.array_equal(bits(S.tris['origin']), bits(want))
+    # root bounds: vertices padded by 0.1 (BVH_builder.cpp:19-24)
+    allv = np.concatenate([hs.tris['a'], hs.tris['b'], hs.tris['c']])
+    assert np.array_equal(nodes['aabbMin'][0], allv.min(0) - np.float32(0.1))
+    assert np.array_equal(nodes['aabbMax'][0], allv.max(0) + np.float32(0.1))
+
+
+def test_tree_boxes_enclose_their_triangles():
+    b = util.soup(2000, seed=21, extent=300.0, edge=10.0)
+    nodes, idx, tris = b.nodes, b.idx, b.tris
+    stack = [0]
+    seen = 0
+    while stack:
+        i = stack.pop()
+        nd = nodes[i]
+        if nd['triCount'] > 0:
+            ids = idx[nd['leftFirst']:nd['leftFirst'] + nd['triCount']]
+            seen += len(ids)
+            for k in ('a', 'b', 'c'):
+                assert np.all(tris[k][ids] >= nd['aabbMin']) and np.all(tris[k][ids] <= nd['aabbMax'])
+        else:
+            for c in (nd['leftFirst'], nd['leftFirst'] + 1):
+                assert np.all(nodes['aabbMin'][c] >= nd['aabbMin'] - 1e-3) and np.all(nodes['aabbMax'][c] <= nd['aabbMax'] + 1e-3)
+                stack.append(int(c))
+    assert seen == len(tris)
+
+
+# ------------------------------------------------------------------ texture sampler, tone map, camera
+def test_bilinear_sampler_hand_values():
+    """Normalized coordinates, wrap addressing, texel centres at +0.5 (image_loader.h:37-45 asks for
+    cudaFilterModeLinear / cudaAddressModeWrap / normalizedCoords)."""
+    t = np.arange(8, dtype=np.float32).reshape(2, 4, 1)        # 4 wide, 2 high: rows [0 1 2 3], [4 5 6 7]
+    assert orc.tex2d(t, 0.125, 0.25)[0] == 0.0                  # centre of texel (0,0)
+    assert orc.tex2d(t, 0.375, 0.25)[0] == 1.0
+    assert orc.tex2d(t, 0.25, 0.25)[0] == 0.5                   # half way between texels 0 and 1
+    assert orc.tex2d(t, 0.125, 0.5)[0] == 2.0                   # half way between the rows
+    assert orc.tex2d(t, 0.0, 0.25)[0] == 1.5                    # wraps: blend of texel 3 and texel 0
+    assert orc.tex2d(t, 1.125, 1.25)[0] == 0.0                  # periodic
+    assert orc.tex2d(t, -0.875, -0.75)[0] == 0.0
+    rgba = np.zeros((1, 2, 4), np.float32); rgba[0, 0] = [1, 2, 3, 4]; rgba[0, 1] = [5, 6, 7, 8]
+    assert np.array_equal(orc.tex2d(rgba, 0.5, 0.5), [3, 4, 5, 6])
+
+
+def test_agx_tonemap_properties():
+    """tonemapping.cuh:17-63: output grows with input, grey stays grey, bytes saturate.  Exact black is a
+    quirk: the contrast polynomial gives -0.00232 at the bottom of the range (:26) and the look's pow of a
+    negative number (:54) is NaN, which the byte conversion turns into 0."""
+    black = orc.agx([0, 0, 0])
+    assert np.all(np.isnan(black))
+    lo = orc.agx([1e-3, 1e-3, 1e-3]); mid = orc.agx([0.18, 0.18, 0.18]); hi = orc.agx([50, 50, 50])
+    assert np.all(lo < 0.05) and np.all(hi > 0.95) and np.all(mid > lo) and np.all(hi > mid)
+    assert np.ptp(mid) < 0.02 and 0.3 < mid[0] < 0.6
+
+    def agx64(c):       # the same formula in float64, written out independently
+        c = np.asarray(c, np.float64)
+        m_in = np.array([[0.842479062253094, 0.0423282422610123, 0.0423756549057051],
+                         [0.0784335999999992, 0.878468636469772, 0.0784336],
+                         [0.0792237451477643, 0.0791661274605434, 0.879142973793104]])
+        x = np.clip(np.log2(m_in @ c), -12.47393, 4.026069)
+        x = (x + 12.47393) / (4.026069 + 12.47393)
+        x = 15.5 * x**6 - 40.14 * x**5 + 31.96 * x**4 - 6.868 * x**3 + 0.4298 * x**2 + 0.1191 * x - 0.00232
+        luma = np.dot([0.2126, 0.7152, 0.0722], x)
+        x = luma + 1.4 * (x**1.35 - luma)
+        m_out = np.array([[1.19687900512017, -0.0528968517574562, -0.0529716355144438],
+                          [-0.0980208811401368, 1.15190312990417, -0.0980434501171241],
+                          [-0.0990297440797205, -0.0989611768448433, 1.15107367264116]])
+        return m_out @ x
+    for c in ([0.18, 0.18, 0.18], [1.0, 0.2, 0.05], [0.01, 0.5, 3.0], [20, 10, 5]):
+        assert np.allclose(orc.agx(c), agx64(c), rtol=2e-4, atol=2e-5)
+    prev = -1.0
+    for v in np.geomspace(1e-3, 100, 60):
+        o = orc.agx([v, v, v])[0]
+        assert o >= prev - 1e-6
+        prev = o
+    acc = np.zeros((1, 4, 3), np.float32)
+    acc[0, 0] = 0; acc[0, 1] = [4, 4, 4]; acc[0, 2] = [1e6, 1e6, 1e6]; acc[0, 3] = [np.nan, 1, 1]
+    img = orc.resolve_display(acc, 4)
+    assert np.all(img[..., 3] == 255)
+    assert np.all(img[0, 0, :3] == 0) and np.all(img[0, 2, :3] >= 240) and img[0, 3, 0] == 0
+    assert np.array_equal(img[0, 1], orc.resolve_display(acc / 4, 1)[0, 1])
+
+
+def test_camera_basis_matches_product_host_code():
+    """pathtracer.cu:568-571 (the rotation of rayDirectionZ by cameraAngle and the derived uu, vv)."""
+    P = ptamd.default_params(64, 48)
+    for ang in [(0, 0, 0), (0.3, -1.2, 0), (-0.7, 2.5, 0.0), (1.2, 0.1, 0)]:
+        P.cameraAngle = ptamd.Float3(*ang)
+        a = orc.camera_basis(P)
+        b = lib.camera_basis(P)
+        for u, v in zip(a, b):
+            assert np.array_equal(bits(u), bits(v))
+        ww, uu, vv = a
+        assert abs(np.dot(ww, uu)) < 1e-5 and abs(np.dot(ww, vv)) < 1e-5 and abs(np.dot(uu, vv)) < 1e-5
+        assert abs(np.linalg.norm(ww) - 1) < 1e-5
+    P.cameraAngle = ptamd.Float3(0, 0, 0)
+    ww, uu, vv = orc.camera_basis(P)
+    assert np.allclose(ww, [0, 0, -1], atol=1e-6)
+
+
+# ------------------------------------------------------------------ environment map
+def _env_scene(w=64, h=32):
+    env = scenes.sky_envmap(w, h, sun_power=40.0)
+    env4 = np.concatenate([env, np.zeros(env.shape[:2] + (1,), np.float32)], -1)
+    tris, mats = scenes.soup(1, seed=1, extent=1.0, edge=1.0)
+    S = orc.Scene(tris, mats)
+    S.set_env(env4)
+    return S, env4
+
+
+def test_env_cdf_matches_product_host_code_and_is_monotone():
+    S, env4 = _env_scene()
+    cdf, total = lib.build_env_cdf(env4)
+    assert np.array_equal(bits(cdf), bits(S.env_cdf)) and np.float32(total) == np.float32(S.env_sum)
+    flat = cdf.ravel()
+    assert np.all(np.diff(flat) >= 0) and flat[-1] == np.float32(total)
+    lum = (0.212671 * env4[..., 0].astype(np.float64) + 0.715160 * env4[..., 1] + 0.072169 * env4[..., 2]).ravel()
+    assert abs(lum.sum() - total) / lum.sum() < 1e-3
+
+
+def test_env_pdf_integrates_to_one_and_sampling_follows_it():
+    """evalEnvmap (envmap_cuda.cu:12-22): pdf = luminance / sum * W*H / (2 pi^2 sin(theta))."""
+    S, env4 = _env_scene()
+    rng = np.random.default_rng(5)
+    n = 20000
+    d = rng.normal(0, 1, (n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    pdf = np.array([orc.env_eval(S, x)[3] for x in d])
+    integral = pdf.mean() * 4 * math.pi
+    assert abs(integral - 1.0) < 0.08
+    # sampled directions are unit vectors whose reported pdf is the pdf of the texel they came from
+    hits_up, pole = 0, 0
+    for k in range(400):
+        dp, col = orc.env_sample(S, k, 0)
+        assert abs(np.linalg.norm(dp[:3]) - 1) < 1e-4
+        if dp[1] == 1.0:          # row 0 maps to theta = 0 exactly (v = y/H without the half texel, envmap_cuda.cu:62-66): sin(theta) = 0 in the pdf
+            pole += 1
+            continue
+        assert dp[3] > 0 and np.all(col >= 0)
+        hits_up += dp[1] > 0
+    assert hits_up > 300 and pole < 40          # the sky half carries almost all of the power
+
+
+# ------------------------------------------------------------------ BSDF
+def _mat(**kw):
+    m = ptamd.default_materials(1)
+    m['baseColor'] = 0.8
+    for k, v in kw.items():
+        m[k] = v
+    return m
+
+
+def test_bsdf_sample_is_consistent_with_eval():
+    """DisneySample_2 returns the value and density DisneyEval_2 gives for the direction it picked
+    (disney.cuh:458-459)."""
+    N = np.array([0, 0, 1], np.float32)
+    V = np.array([0.3, 0.1, 0.9], np.float32); V /= np.linalg.norm(V)
+    for m in (_mat(roughness=1.0), _mat(roughness=0.3, metallic=1.0), _mat(roughness=0.5, clearcoat=1.0, sheen=0.5),
+              _mat(roughness=0.2, specTrans=1.0, ior=1.5)):
+        checked = 0
+        for k in range(200):
+            L, f, pdf, ins = orc.bsdf_sample(m, 0, V, N, k, 1)
+            if not (pdf > 0):
+                continue
+            f2, pdf2 = orc.bsdf_eval(m, 0, V, N, L)
+            assert np.allclose(f, f2, rtol=1e-5, atol=1e-7) and abs(pdf - pdf2) <= 1e-5 * max(pdf, 1)
+            assert abs(np.linalg.norm(L) - 1) < 1e-3
+            checked += 1
+        assert checked > 100
+
+
+def test_rough_dielectric_is_nearly_lambertian_and_conserves_energy():
+    N = np.array([0, 0, 1], np.float32)
+    V = np.array([0, 0, 1], np.float32)
+    m = _mat(roughness=1.0)
+    rng = np.random.default_rng(2)
+    n = 4000
+    d = rng.normal(0, 1, (n, 3)); d[:, 2] = np.abs(d[:, 2]); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    tot = np.zeros(3)
+    pdf_int = 0.0
+    for L in d.astype(np.float32):
+        f, pdf = orc.bsdf_eval(m, 0, V, N, L)
+        assert np.all(f >= 0) and pdf >= 0
+        tot += f                       # DisneyEval_2 already includes the cosine (disney.cuh:352)
+        pdf_int += pdf
+    albedo = tot / n * 2 * math.pi
+    assert np.all(albedo < 1.0) and np.all(albedo > 0.5)
+    assert abs(pdf_int / n * 2 * math.pi - 1.0) < 0.1
+    f, pdf = orc.bsdf_eval(m, 0, V, N, np.array([0, 0, -1], np.float32))
+    assert np.all(f == 0)              # no transmission through an opaque surface
+
+
+def test_sky_gradient_brightest_toward_the_sun():
+    sun = np.array([1, 0.7, -1], np.float32); sun /= np.linalg.norm(sun)
+    at_sun = orc.sky_gradient(sun, sun)
+    away = orc.sky_gradient(-sun * np.array([1, -1, 1], np.float32), sun)
+    assert np.all(at_sun >= away) and at_sun.sum() > away.sum() and np.all(away >= 0)
+
+
+# ------------------------------------------------------------------ whole samples
+def test_render_is_deterministic_and_frames_compose():
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(24, 24))
+    S = b.oracle(P)
+    a, st = orc.render(S, P, 0, 4, 6)
+    a2, st2 = orc.render(S, P, 0, 4, 6, nthreads=1)
+    assert np.array_equal(bits(a), bits(a2)) and st == st2
+    part, _ = orc.render(S, P, 0, 2, 6)
+    part, _ = orc.render(S, P, 2, 4, 6, accum=part)
+    assert np.array_equal(bits(a), bits(part))
+    assert st['samples'] == 24 * 24 * 4 and st['rays'] >= st['samples']
+    # one colour channel per sample (pathtracer.cu:527-540): a single sample lights at most one channel
+    one, _ = orc.render(S, P, 5, 6, 6)
+    assert np.all((one > 0).sum(-1) <= 1)
+    rgb, _ = orc.pixel_sample(S, P, 3, 7, 5, 6)
+    assert np.array_equal(bits(rgb), bits(one[7, 3]))
+
+
+def test_cornell_emitter_only_lighting():
+    """Black environment: light reaches the image only through the ceiling emitter (Ke 15)."""
+    b = util.cornell('black')
+    P = scenes.cornell_params(ptamd.default_params(32, 32))
+    acc, st = orc.render(b.oracle(P), P, 0, 8, 4)
+    assert acc.sum() > 0 and st['env_samples'] > 0
+    img = orc.resolve_display(acc, 8)
+    assert img[..., :3].max() > 100
+    P.isRendering = 0              # preview: N.V shading of the base colour, one ray per sample (pathtracer.cu:504-525)
+    prev, st = orc.render(b.oracle(P), P, 0, 1, 4)
+    assert st['rays'] == st['samples'] == 32 * 32 and prev.max() <= 3.0 * 0.78 + 1e-4
+
+
+# ------------------------------------------------------------------ committed golden vectors
+def test_oracle_reproduces_committed_golden_vectors():
+    """tests/golden/vectors.npz was written by tests/golden/make_golden.py from this oracle; it pins the oracle
+    against drift (compiler, flags, edits) and gives the GPU tests a fixed target that needs no oracle run."""
+    g = np.load(os.path.join(GOLDEN, 'vectors.npz'))
+    assert np.array_equal(orc.uniform_stream(int(g['stream_pixel']), int(g['stream_frame']), len(g['stream'])), g['stream'])
+    out = orc.detmath_probe(g['probe_x'], g['probe_y'])
+    assert np.array_equal(bits(out), g['probe_bits'])
+    from make_golden import bunny_bundle, cornell_bundle
+    bb = bunny_bundle()
+    assert np.array_equal(bb.nodes, g['bunny_nodes'].view(ptamd.NODE_DTYPE).ravel()) and np.array_equal(bb.idx, g['bunny_idx'])
+    rays = g['bunny_rays'].view(RAY_DTYPE).ravel()
+    h = orc.closest_brute(bb.oracle(), rays)
+    assert np.array_equal(h['tri'], g['bunny_hit_tri']) and np.array_equal(bits(h['t']), g['bunny_hit_t_bits'])
+    cb, P = cornell_bundle()
+    acc, st = orc.render(cb.oracle(P), P, 0, int(g['cornell_frames']), int(g['cornell_bounces']))
+    assert np.array_equal(bits(acc), g['cornell_accum_bits'])
+    assert st['rays'] == int(g['cornell_rays'])
+    assert np.array_equal(orc.resolve_display(acc, int(g['cornell_frames'])), g['cornell_rgba'])

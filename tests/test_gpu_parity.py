@@ -170,7 +170,7 @@ def test_sun_sky_mode_glossy_dielectric(mode):
     assert ctr['rays'] == st['rays']
 
 
-@pytest.mark.parametrize('pool', [(64, 1), (320, 3), (1 << 14, 64)])
+@pytest.mark.parametrize('pool', [(64, 1), (320, 3), (320, 2), (512, 5), (1 << 14, 64)])
 def test_wavefront_pool_size_does_not_change_results(pool):
     """Tiny pools force slot regeneration, retirement and several staging chunks; odd image size
     exercises the row-major sample order."""
@@ -216,3 +216,99 @@ def test_frame_ranges_compose():
     parts = r.read_accum()
     assert np.array_equal(bits(whole), bits(parts))
     r.close()
+
+
+def test_small_pools_repeat_exactly():
+    """Slot regeneration near the end of a render (slots retiring while other workgroups still hold unissued
+    sample ids) must not depend on scheduling: the same render ten times gives the same bits."""
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(37, 29))
+    want, _ = orc.render(b.oracle(P), P, 1, 6, 12)
+    r = b.renderer(P)
+    r.set_max_bounces(12)
+    for rep in range(5):
+        for pool in ((320, 2), (512, 5)):
+            r.set_pool(*pool)
+            r.clear_accum()
+            r.render(P, 1, 6)
+            _assert_radiance(r.read_accum(), want)
+    r.close()
+
+
+def test_production_traversal_kernel_matches_brute_force():
+    """pt_trace_closest_fast runs the persistent-wave kernel of the render path (quantized node boxes, leaf
+    votes, lane refill); its hits must be the exact ones."""
+    b = util.atrium(detail=0.35)
+    P = scenes.atrium_params(ptamd.default_params(64, 64))
+    rays = scenes.random_rays(300000, seed=15, extent=1400.0)
+    rays['o'][:, 1] = np.abs(rays['o'][:, 1]) * 0.8
+    rays['d'][5] = [np.nan, 0, 1]; rays['o'][6] = [np.inf, 0, 0]; rays['d'][7] = [0, 0, 0]
+    r = b.renderer(P)
+    fast = r.trace_closest_fast(rays)
+    slow = r.trace_closest(rays)
+    assert np.array_equal(fast['tri'], slow['tri']) and np.array_equal(bits(fast['t']), bits(slow['t']))
+    brute = orc.closest_brute(b.oracle(), rays[:3000])
+    assert np.array_equal(fast['tri'][:3000], brute['tri']) and np.array_equal(bits(fast['t'][:3000]), bits(brute['t']))
+    for n in (1, 63, 257):      # ragged sizes
+        part = r.trace_closest_fast(rays[:n])
+        assert np.array_equal(part['tri'], slow['tri'][:n]) and np.array_equal(bits(part['t']), bits(slow['t'][:n]))
+    r.close()
+
+
+def test_committed_golden_vectors():
+    """The HIP path against tests/golden/vectors.npz (no oracle run involved)."""
+    import os
+    from make_golden import bunny_bundle, cornell_bundle
+    from ptamd.types import RAY_DTYPE
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'vectors.npz'))
+    bb = bunny_bundle()
+    assert np.array_equal(bb.nodes, g['bunny_nodes'].view(ptamd.NODE_DTYPE).ravel())
+    rays = g['bunny_rays'].view(RAY_DTYPE).ravel()
+    r = bb.renderer(ptamd.default_params(16, 16))
+    for h in (r.trace_closest(rays), r.trace_closest_fast(rays)):
+        assert np.array_equal(h['tri'], g['bunny_hit_tri']) and np.array_equal(bits(h['t']), g['bunny_hit_t_bits'])
+    probe = r.detmath_probe(g['probe_x'], g['probe_y'])
+    assert np.array_equal(bits(probe), g['probe_bits'])
+    r.close()
+    cb, P = cornell_bundle()
+    for mode in (0, 1):
+        r = cb.renderer(P)
+        r.set_mode(mode)
+        r.set_max_bounces(int(g['cornell_bounces']))
+        r.enable_counters(True)
+        r.render(P, 0, int(g['cornell_frames']))
+        assert np.array_equal(bits(r.read_accum()), g['cornell_accum_bits'])
+        assert r.counters()['rays'] == int(g['cornell_rays'])
+        assert np.array_equal(r.resolve_display(int(g['cornell_frames'])), g['cornell_rgba'])
+        r.close()
+
+
+def test_full_size_render_properties():
+    """At the benchmark's size (1920x1080, the 262k-triangle atrium) the oracle is too slow to run whole, so the
+    test uses properties that do not depend on size: the two kernel organisations agree bit for bit, frame ranges
+    compose, and a band of rows equals the oracle's render of those rows."""
+    b = util.atrium()
+    W, H = 1920, 1080
+    P = scenes.atrium_params(ptamd.default_params(W, H))
+    r = b.renderer(P)
+    r.render(P, 0, 3)
+    wave = r.read_accum()
+    r.clear_accum()
+    r.render(P, 0, 1)
+    r.render(P, 1, 3)
+    assert np.array_equal(bits(r.read_accum()), bits(wave))
+    r.set_mode(1)
+    r.clear_accum()
+    r.render(P, 0, 3)
+    assert np.array_equal(bits(r.read_accum()), bits(wave))
+    r.close()
+    assert np.isfinite(wave).all() and wave.min() >= 0 and wave.mean() > 0.01
+    # oracle on a sparse sample of pixels (a few hundred single-pixel evaluations)
+    S = b.oracle(P)
+    rng = np.random.default_rng(8)
+    for x, y in zip(rng.integers(0, W, 150), rng.integers(0, H, 150)):
+        acc = np.zeros(3, np.float32)
+        for f in range(3):
+            rgb, _ = orc.pixel_sample(S, P, int(x), int(y), f, 512)
+            acc = acc + rgb
+        assert np.array_equal(bits(acc), bits(wave[y, x])), (x, y)
