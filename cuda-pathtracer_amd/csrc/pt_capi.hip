@@ -516,6 +516,8 @@ static int wf_prepare(pt_ctx* c, int frames, WfParams* w)
     w->bsdf_queue = (uint32_t*)(base + (size_t)13 * slots);
     w->bsdf_count = w->bsdf_queue + slots;
     w->block_chunk = w->bsdf_count + slots / 256;
+    w->chunk_rays = w->block_chunk + 2 * (slots / 256);
+    w->chunk_list = w->chunk_rays + slots / 256;
     w->counters = c->wf_counters;
     w->staging = c->wf_staging;
     w->n_slots = (int)slots;
@@ -731,8 +733,10 @@ int pt_trace_closest_fast_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* 
     WfParams w{};
     float4* base = (float4*)c->wf_block;
     w.ray_o = base; w.ray_d = base + slots; w.hit = base + 2 * slots;
+    w.chunk_rays = (uint32_t*)(base + (size_t)13 * slots) + slots + slots / 256 + 2 * (slots / 256);
+    w.chunk_list = w.chunk_rays + slots / 256;
     w.counters = c->wf_counters;
-    w.n_slots = n;
+    w.n_slots = (int)slots;
     w.refill_lanes = c->refill_lanes; w.leaf_vote = c->leaf_vote; w.extend_blocks = c->extend_blocks_per_cu * c->n_cus;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     launch_wf_trace(w, c->scene, rays_dev, n, hits_dev, c->stream);

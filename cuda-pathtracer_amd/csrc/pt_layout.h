@@ -80,7 +80,7 @@ struct DCounters {
 
 // ---------------------------------------------------------------- wavefront pool
 // Path slots as a structure of 16-byte arrays (slot-indexed) plus the per-sample staging values.
-enum : int { WF_CTR_NEXT_SAMPLE = 0, WF_CTR_BSDF_COUNT = 1, WF_CTR_LIVE = 2, WF_CTR_LIVE_PREV = 3, WF_CTR_RAY_NEXT = 4, WF_CTR_WORDS = 8 };
+enum : int { WF_CTR_NEXT_SAMPLE = 0, WF_CTR_BSDF_COUNT = 1, WF_CTR_LIVE = 2, WF_CTR_LIVE_PREV = 3, WF_CTR_RAY_NEXT = 4, WF_CTR_RAY_CHUNKS = 5, WF_CTR_RAYS = 6, WF_CTR_WORDS = 8 };
 struct WfParams {
     float4 *ray_o, *ray_d;          // pending ray; ray_d.w != 0 when the slot has a ray to trace
     float4 *hit;                    // (t, triangle, u, v)
@@ -90,6 +90,8 @@ struct WfParams {
     uint32_t* bsdf_queue;           // [n_slots], one 256-entry segment per workgroup
     uint32_t* bsdf_count;           // [n_slots/256] entries used in each segment
     uint32_t* block_chunk;          // [n_slots/256][2] cursor/end of the sample-id chunk each workgroup owns
+    uint32_t* chunk_rays;           // [n_slots/256] rays waiting in each block of 256 slots (written by the stages that make rays)
+    uint32_t* chunk_list;           // [n_slots/256] blocks with at least one ray, compacted before each extend launch
     uint32_t* counters;
     float* staging;                 // n_frames * W * H sample values of the current chunk
     int n_slots;

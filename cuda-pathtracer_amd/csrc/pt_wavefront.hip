@@ -216,6 +216,20 @@ PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_
     if (threadIdx.x == 0) { cw[0] = s_chunk[0]; cw[1] = s_chunk[1]; }
 }
 
+// Number of threads of the workgroup for which pred holds; every thread must call it.
+PT_DEV uint32_t block_count(bool pred)
+{
+    __shared__ uint32_t s_c[kBlock / 64];
+    unsigned long long m = __ballot(pred);
+    if ((threadIdx.x & 63u) == 0) s_c[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t total = 0;
+#pragma unroll
+    for (int j = 0; j < kBlock / 64; j++) total += s_c[j];
+    __syncthreads();
+    return total;
+}
+
 // First fill of the pool: like finish_and_regenerate with every slot "finished", except that there is
 // no previous sample to publish.
 template <bool COUNT>
@@ -281,6 +295,10 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
     store_ray(w, slot, P);
     store_core(w, slot, P, sample);
     store_light(w, slot, P);
+    {
+        uint32_t nr = block_count(P.state != ST_DONE);
+        if (threadIdx.x == 0) w.chunk_rays[blockIdx.x] = nr;
+    }
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
@@ -337,6 +355,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     bool has_ray = false;
     bool more = true;
     uint32_t chunk_next = 0, chunk_end = 0;      // wave-uniform
+    const uint32_t n_chunks = w.counters[WF_CTR_RAY_CHUNKS];
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
 #if PT_STAMPS
     unsigned long long st_iters = 0, st_lanes = 0, st_leafphases = 0, st_refills = 0, st_t0 = __builtin_amdgcn_s_memtime();
@@ -388,14 +407,18 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         uint32_t idx = 0;
         float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4;
         if (do_refill) {
-            // rays are handed out from a wave-private chunk of consecutive slots; one global atomic per chunk
+            // rays are handed out in blocks of kRayChunk consecutive slots, taken with one atomic each from the
+            // list of blocks that hold rays (a static deal of list entries to waves was measured slower)
             if (chunk_next >= chunk_end) {
-                uint32_t c = 0;
-                if (lane == 0) c = atomicAdd(w.counters + WF_CTR_RAY_NEXT, (uint32_t)kRayChunk);
-                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                chunk_next = c;
-                chunk_end = c + kRayChunk < (uint32_t)w.n_slots ? c + kRayChunk : (uint32_t)w.n_slots;
-                if (c >= (uint32_t)w.n_slots) { more = false; chunk_end = chunk_next; }
+                uint32_t li = 0;
+                if (lane == 0) li = atomicAdd(w.counters + WF_CTR_RAY_NEXT, 1u);
+                li = (uint32_t)__builtin_amdgcn_readfirstlane((int)li);
+                if (li >= n_chunks) { more = false; chunk_end = chunk_next; }
+                else {
+                    uint32_t c = w.chunk_list[li] * (uint32_t)kRayChunk;
+                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                    chunk_next = c; chunk_end = c + kRayChunk;
+                }
             }
             const uint32_t avail = chunk_end - chunk_next;
             const uint32_t rank = (uint32_t)__popcll(idle_mask & ((1ull << lane) - 1ull));
@@ -559,6 +582,11 @@ __global__ __launch_bounds__(kBlock) void wf_shade_kernel(WfParams w, DScene S, 
         store_light(w, slot, P);
     }
     bool alive = live && (P.state != ST_DONE);
+    {
+        // rays this block hands to the next extend launch (slots on their way to the bsdf stage add theirs there)
+        uint32_t nr = block_count(alive && P.state != ST_AFTER);
+        if (threadIdx.x == 0) w.chunk_rays[blockIdx.x] = nr;
+    }
     if (__any(alive) && (threadIdx.x & 63u) == 0) w.counters[WF_CTR_LIVE] = 1u;     // a flag, not a count: plain store
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
@@ -594,6 +622,10 @@ __global__ __launch_bounds__(kBlock) void wf_bsdf_kernel(WfParams w, DScene S, D
         store_core(w, slot, P, sample);
         store_light(w, slot, P);
     }
+    {
+        uint32_t nr = block_count(active && P.state != ST_DONE);
+        if (threadIdx.x == 0) w.chunk_rays[blockIdx.x] += nr;      // the shade launch wrote this block's count
+    }
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
 
@@ -619,18 +651,59 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate_kernel(WfParams w, DCame
 }
 
 // ---------------------------------------------------------------- closest-hit batch through the production traversal
-__global__ void wf_reset_iteration_kernel(uint32_t* counters)
+// Runs before every extend launch (one workgroup): compacts the indices of the slot blocks that hold rays
+// into chunk_list, publishes their number, and resets the per-iteration counters.
+constexpr int kPlanThreads = 1024;
+__global__ __launch_bounds__(kPlanThreads) void wf_plan_extend_kernel(uint32_t* __restrict__ counters, const uint32_t* __restrict__ chunk_rays,
+                                                                      uint32_t* __restrict__ chunk_list, int n_chunks)
 {
-    counters[WF_CTR_LIVE_PREV] = counters[WF_CTR_LIVE];
-    counters[WF_CTR_LIVE] = 0;
-    counters[WF_CTR_BSDF_COUNT] = 0;
-    counters[WF_CTR_RAY_NEXT] = 0;
+    __shared__ uint32_t s_wave[kPlanThreads / 64];
+    __shared__ uint32_t s_rays[kPlanThreads / 64];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t base = 0, rays = 0;
+    for (int tile = 0; tile < n_chunks; tile += kPlanThreads * 4) {
+        int i0 = tile + tid * 4;
+        uint32_t r[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) r[k] = (i0 + k < n_chunks) ? chunk_rays[i0 + k] : 0u;
+        uint32_t mine = (r[0] != 0) + (r[1] != 0) + (r[2] != 0) + (r[3] != 0);
+        uint32_t rsum = r[0] + r[1] + r[2] + r[3];
+        uint32_t incl = mine;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            uint32_t t = (uint32_t)__shfl_up((int)incl, dlt, 64);
+            uint32_t tr = (uint32_t)__shfl_xor((int)rsum, dlt, 64);
+            if (lane >= dlt) incl += t;
+            rsum += tr;
+        }
+        if (lane == 63) s_wave[wid] = incl;
+        if (lane == 0) s_rays[wid] = rsum;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < kPlanThreads / 64; j++) { uint32_t c = s_wave[j]; if (j < wid) woff += c; total += c; rays += s_rays[j]; }
+        uint32_t pos = base + woff + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (r[k] != 0) chunk_list[pos++] = (uint32_t)(i0 + k);
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        counters[WF_CTR_LIVE_PREV] = counters[WF_CTR_LIVE];
+        counters[WF_CTR_LIVE] = 0;
+        counters[WF_CTR_BSDF_COUNT] = 0;
+        counters[WF_CTR_RAY_NEXT] = 0;
+        counters[WF_CTR_RAY_CHUNKS] = base;
+        counters[WF_CTR_RAYS] = rays;
+    }
 }
 
-__global__ __launch_bounds__(kBlock) void wf_pack_rays_kernel(const pt_ray* __restrict__ rays, int n, float4* __restrict__ ray_o, float4* __restrict__ ray_d)
+__global__ __launch_bounds__(kBlock) void wf_pack_rays_kernel(const pt_ray* __restrict__ rays, int n, float4* __restrict__ ray_o, float4* __restrict__ ray_d,
+                                                              uint32_t* __restrict__ chunk_rays)
 {
-    int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
+    int i = blockIdx.x * kBlock + threadIdx.x;      // the grid covers n rounded up to whole blocks
+    if (threadIdx.x == 0) chunk_rays[blockIdx.x] = (uint32_t)((n - (int)(blockIdx.x * kBlock)) < kBlock ? (n - (int)(blockIdx.x * kBlock)) : kBlock);
+    if (i >= n) { ray_d[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(0)); return; }
     const float4* r = reinterpret_cast<const float4*>(rays + i);
     float4 o = r[0], d = r[1];
     ray_o[i] = make_float4(o.x, o.y, o.z, 0.f);
@@ -647,8 +720,8 @@ __global__ __launch_bounds__(kBlock) void wf_unpack_hits_kernel(const float4* __
 void launch_wf_trace(const WfParams& w, const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, hipStream_t s)
 {
     dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
-    hipLaunchKernelGGL(wf_pack_rays_kernel, grid, block, 0, s, rays_dev, n, w.ray_o, w.ray_d);
-    hipLaunchKernelGGL(wf_reset_iteration_kernel, dim3(1), dim3(1), 0, s, w.counters);
+    hipLaunchKernelGGL(wf_pack_rays_kernel, grid, block, 0, s, rays_dev, n, w.ray_o, w.ray_d, w.chunk_rays);
+    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, (int)grid.x);
     int ext_blocks = (int)grid.x < w.extend_blocks ? (int)grid.x : w.extend_blocks;
     hipLaunchKernelGGL(wf_extend_kernel<false>, dim3(ext_blocks), block, 0, s, w, S, (DCounters*)nullptr);
     hipLaunchKernelGGL(wf_unpack_hits_kernel, grid, block, 0, s, w.hit, n, hits_dev);
@@ -665,7 +738,7 @@ void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, h
 void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t ext0, hipEvent_t ext1)
 {
     dim3 grid((w.n_slots + kBlock - 1) / kBlock), block(kBlock);
-    hipLaunchKernelGGL(wf_reset_iteration_kernel, dim3(1), dim3(1), 0, s, w.counters);
+    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, w.n_slots / kBlock);
     if (ext0) (void)hipEventRecord(ext0, s);
     // persistent waves: enough workgroups to fill every CU, each pulls rays until the pool is drained
     int ext_blocks = (w.n_slots + kBlock - 1) / kBlock;
