@@ -3,7 +3,7 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-Workload (BASELINE.json configs[1]): the Sponza-class atrium (about 262k triangles, 25 PBR materials
+Workload: the Sponza-class atrium (about 262k triangles, 25 PBR materials
 with texture maps, 1024x512 HDR environment), 1920x1080, 64 samples per pixel per GPU per step, bounce
 cap 512 as in the reference.  One step = clear the accumulator, render this rank's 64 frames, sum the
 per-GPU accumulators on rank 0 (RCCL reduce, N > 1 only), resolve to RGBA8.  Ranks render disjoint
