@@ -49,6 +49,7 @@ def main():
     ap.add_argument('--cpu-spp', type=int, default=12, help='frames the CPU oracle renders for the baseline (about 15 s on 16 cores)')
     ap.add_argument('--mode', choices=['wavefront', 'single_kernel'], default='wavefront')
     ap.add_argument('--pool', type=int, default=0, help='wavefront pool slots (0 = library default)')
+    ap.add_argument('--node-width', type=int, default=4, help='4-wide or binary (2) compact nodes in the traversal kernel')
     ap.add_argument('--tune', type=str, default='', help='refill_lanes,leaf_vote,blocks_per_cu for the traversal kernel')
     args = ap.parse_args()
 
@@ -81,6 +82,7 @@ def main():
     r.set_mode(0 if args.mode == 'wavefront' else 1)
     if args.pool:
         r.set_pool(args.pool, 64)
+    r.set_node_width(args.node_width)
     if args.tune:
         r.set_extend_tuning(*[int(x) for x in args.tune.split(',')])
     stream = torch.cuda.current_stream()

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <functional>
 #include <new>
 #include "../../include/pt_capi.h"
 #include "../../include/pt_detmath.h"
@@ -41,6 +42,10 @@ struct pt_ctx {
     DTri* d_tris = nullptr;
     DNode* d_nodes = nullptr;
     DNodeQ* d_qnodes = nullptr;
+    DNode4* d_nodes4 = nullptr;
+    bool wide_fits = false;
+    int node_width = 4;
+    int leaf_merge = 2;
     DMat* d_mats = nullptr;
     DTex* d_tex = nullptr;
     std::vector<DTex> tex_table;
@@ -110,6 +115,7 @@ static void free_scene_geometry(pt_ctx* c)
     if (c->d_tris) { (void)hipFree(c->d_tris); c->d_tris = nullptr; }
     if (c->d_nodes) { (void)hipFree(c->d_nodes); c->d_nodes = nullptr; }
     if (c->d_qnodes) { (void)hipFree(c->d_qnodes); c->d_qnodes = nullptr; }
+    if (c->d_nodes4) { (void)hipFree(c->d_nodes4); c->d_nodes4 = nullptr; }
     c->have_bvh = false;
 }
 
@@ -315,6 +321,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     c->scene.root_max[0] = root.aabbMax.x; c->scene.root_max[1] = root.aabbMax.y; c->scene.root_max[2] = root.aabbMax.z;
     // 16-bit grid over the (padded) root box for the compact nodes
     std::vector<DNodeQ> qn(dn.size());
+    std::function<uint16_t(float, int)> qlo_f, qhi_f;
     {
         double org[3] = {root.aabbMin.x, root.aabbMin.y, root.aabbMin.z};
         double ext[3] = {(double)root.aabbMax.x - root.aabbMin.x, (double)root.aabbMax.y - root.aabbMin.y, (double)root.aabbMax.z - root.aabbMin.z};
@@ -328,6 +335,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
         }
         auto qlo = [&](float v, int a) { double q = std::floor(((double)v - (double)c->scene.q_origin[a]) / (double)c->scene.q_cell[a]) - 2.0; return (uint16_t)(q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q)); };
         auto qhi = [&](float v, int a) { double q = std::ceil(((double)v - (double)c->scene.q_origin[a]) / (double)c->scene.q_cell[a]) + 2.0; return (uint16_t)(q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q)); };
+        qlo_f = qlo; qhi_f = qhi;
         for (size_t i = 0; i < dn.size(); i++) {
             const DNode& s = dn[i];
             DNodeQ& t = qn[i];
@@ -338,8 +346,94 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
             t.left = s.left; t.right = s.right;
         }
     }
+    // four-wide nodes: each binary node's children are replaced by their own children, largest box first,
+    // until four are present; absorbed binary nodes disappear
+    std::vector<DNode4> n4;
+    int stack_need_binary = 0, stack_need_wide = 0;
+    {
+        // stack need of the binary walk: one pending sibling per level
+        std::vector<std::pair<int, int>> st;
+        if (c->scene.root_ref >= 0) st.push_back({0, 1});
+        while (!st.empty()) {
+            auto [i, need] = st.back(); st.pop_back();
+            if (need > stack_need_binary) stack_need_binary = need;
+            if (dn[i].left >= 0) st.push_back({dn[i].left, need + 1});
+            if (dn[i].right >= 0) st.push_back({dn[i].right, need + 1});
+        }
+    }
+    // Leaves of the wide tree: a binary subtree with at most leaf_merge triangles becomes one leaf. Its triangle
+    // records are contiguous because subtrees are emitted whole. A wide leaf reference carries its own
+    // count: ~(first | (count - 1) << 26).
+    const int leaf_merge = c->leaf_merge;
+    bool wide_ok = dt.size() < ((size_t)1 << 26);
+    auto wide_leaf = [](int first, int count) { return ~(int)((uint32_t)first | ((uint32_t)(count - 1) << 26)); };
+    std::vector<int> sub_first(dn.size(), 0), sub_count(dn.size(), 0);
+    auto leaf_count = [&](int ref) { return __builtin_bit_cast(int, dt[(size_t)~ref].q1.w); };
+    if (c->scene.root_ref >= 0) {
+        // children have larger indices than their parents: a reverse sweep sees children first
+        for (int i = (int)dn.size() - 1; i >= 0; i--) {
+            int fl, cl, fr, cr;
+            if (dn[i].left < 0) { fl = ~dn[i].left; cl = leaf_count(dn[i].left); } else { fl = sub_first[dn[i].left]; cl = sub_count[dn[i].left]; }
+            if (dn[i].right < 0) { fr = ~dn[i].right; cr = leaf_count(dn[i].right); } else { fr = sub_first[dn[i].right]; cr = sub_count[dn[i].right]; }
+            sub_first[i] = fl < fr ? fl : fr;
+            sub_count[i] = cl + cr;
+        }
+    }
+    auto wide_ref = [&](int ref) -> int {       // binary reference -> wide reference (interior stays >= 0, to be renumbered)
+        if (ref < 0) { int n = leaf_count(ref); if (n > 16) wide_ok = false; return wide_leaf(~ref, n > 16 ? 16 : n); }
+        if (sub_count[ref] <= leaf_merge && sub_count[ref] <= 16) return wide_leaf(sub_first[ref], sub_count[ref]);
+        return ref;
+    };
+    if (c->scene.root_ref >= 0 && wide_ref(0) >= 0) {
+        struct Cand { int ref; const float* lo; const float* hi; };      // ref: wide leaf (< 0) or binary interior index
+        struct Item { int src, dst, need; };
+        std::vector<Item> st;
+        n4.push_back(DNode4{});
+        st.push_back(Item{0, 0, 0});
+        auto area = [](const Cand& k) { double x = (double)k.hi[0] - k.lo[0], y = (double)k.hi[1] - k.lo[1], z = (double)k.hi[2] - k.lo[2]; return x * y + y * z + z * x; };
+        while (!st.empty()) {
+            Item it = st.back(); st.pop_back();
+            std::vector<Cand> cand;
+            cand.push_back(Cand{wide_ref(dn[it.src].left), dn[it.src].lmin, dn[it.src].lmax});
+            cand.push_back(Cand{wide_ref(dn[it.src].right), dn[it.src].rmin, dn[it.src].rmax});
+            while (cand.size() < 4) {
+                int pick = -1; double best = -1.0;
+                for (size_t k = 0; k < cand.size(); k++) if (cand[k].ref >= 0 && area(cand[k]) > best) { best = area(cand[k]); pick = (int)k; }
+                if (pick < 0) break;
+                const DNode& s = dn[cand[pick].ref];
+                cand[pick] = Cand{wide_ref(s.left), s.lmin, s.lmax};
+                cand.push_back(Cand{wide_ref(s.right), s.rmin, s.rmax});
+            }
+            DNode4 d{};
+            int need = it.need + (int)cand.size() - 1;
+            if (need > stack_need_wide) stack_need_wide = need;
+            for (int k = 0; k < 4; k++) {
+                if (k >= (int)cand.size()) { d.ref[k] = (int)0x80000000; continue; }
+                uint32_t lo[3], hi[3];
+                for (int a = 0; a < 3; a++) { lo[a] = (uint32_t)qlo_f(cand[k].lo[a], a); hi[a] = (uint32_t)qhi_f(cand[k].hi[a], a); }
+                d.w[3 * k] = lo[0] | (lo[1] << 16); d.w[3 * k + 1] = lo[2] | (hi[0] << 16); d.w[3 * k + 2] = hi[1] | (hi[2] << 16);
+                if (cand[k].ref >= 0) {
+                    d.ref[k] = (int)n4.size();
+                    n4.push_back(DNode4{});
+                    st.push_back(Item{cand[k].ref, d.ref[k], need});
+                } else d.ref[k] = cand[k].ref;
+            }
+            n4[it.dst] = d;
+        }
+        c->scene.root_ref4 = 0;
+    } else {
+        n4.push_back(DNode4{});
+        c->scene.root_ref4 = wide_ref(c->scene.root_ref >= 0 ? 0 : c->scene.root_ref);
+    }
+    const int stack_capacity = 16 + 48      /* LDS entries + private spill entries of the traversal kernels */;
+    if (stack_need_binary > stack_capacity) { set_error("pt_upload_bvh: tree depth %d exceeds the traversal stack of %d entries", stack_need_binary, stack_capacity); return PT_ERR_ARG; }
+    c->wide_fits = wide_ok && stack_need_wide <= stack_capacity;
+    c->scene.wide = (c->wide_fits && c->node_width == 4) ? 1 : 0;
     free_scene_geometry(c);
     HIP_TRY(hipMalloc((void**)&c->d_qnodes, qn.size() * sizeof(DNodeQ)));
+    HIP_TRY(hipMalloc((void**)&c->d_nodes4, n4.size() * sizeof(DNode4)));
+    HIP_TRY(hipMemcpy(c->d_nodes4, n4.data(), n4.size() * sizeof(DNode4), hipMemcpyHostToDevice));
+    c->scene.nodes4 = c->d_nodes4;
     HIP_TRY(hipMemcpy(c->d_qnodes, qn.data(), qn.size() * sizeof(DNodeQ), hipMemcpyHostToDevice));
     c->scene.qnodes = c->d_qnodes;
     HIP_TRY(hipMalloc((void**)&c->d_nodes, dn.size() * sizeof(DNode)));
@@ -589,6 +683,15 @@ int pt_set_extend_tuning(pt_ctx* c, int refill_lanes, int leaf_vote, int blocks_
 {
     if (!c || refill_lanes < 1 || refill_lanes > 64 || leaf_vote < 1 || leaf_vote > 64 || blocks_per_cu < 1 || blocks_per_cu > 5) { set_error("pt_set_extend_tuning: bad argument"); return PT_ERR_ARG; }
     c->refill_lanes = refill_lanes; c->leaf_vote = leaf_vote; c->extend_blocks_per_cu = blocks_per_cu;
+    return PT_OK;
+}
+
+int pt_set_node_width(pt_ctx* c, int width, int leaf_merge)
+{
+    if (!c || (width != 2 && width != 4) || leaf_merge < 1 || leaf_merge > 16) { set_error("pt_set_node_width: width must be 2 or 4, leaf_merge 1..16"); return PT_ERR_ARG; }
+    c->node_width = width;
+    c->leaf_merge = leaf_merge;         // takes effect at the next pt_upload_bvh / pt_build_bvh
+    c->scene.wide = (c->wide_fits && width == 4) ? 1 : 0;
     return PT_OK;
 }
 

@@ -28,6 +28,16 @@ struct __attribute__((aligned(32))) DNodeQ {
 };
 static_assert(sizeof(DNodeQ) == 32, "compact node must be 32 bytes");
 
+// Four-wide interior node for the production traversal kernel, 64 bytes = one cache line: up to four
+// child boxes on the same 16-bit grid as DNodeQ and their references (PT_TRAV_EMPTY marks an unused
+// child). Made by pulling grandchildren of the binary tree up into their grandparent, largest box
+// first, which halves the number of dependent node fetches per ray.
+struct __attribute__((aligned(64))) DNode4 {
+    uint32_t w[12];       // child k: w[3k] = min.x | min.y << 16, w[3k+1] = min.z | max.x << 16, w[3k+2] = max.y | max.z << 16
+    int ref[4];           // as DNode
+};
+static_assert(sizeof(DNode4) == 64, "wide node must be 64 bytes");
+
 // Triangle record for intersection, 48 bytes = three 16-byte loads, stored in leaf order.
 // q0 = (a.xyz, original index), q1 = (b-a, triangles in this leaf [first record only]), q2 = (c-a, 0)
 struct __attribute__((aligned(16))) DTri { float4 q0, q1, q2; };
@@ -48,6 +58,9 @@ struct DTex { const float* texels; int w, h, comps, pad; };
 struct DScene {
     const DNode* nodes;
     const DNodeQ* qnodes;         // same numbering as nodes
+    const DNode4* nodes4;         // own numbering; root is node 0
+    int wide;                     // 1: the production kernel walks nodes4 (its stack need fits), 0: qnodes
+    int root_ref4;
     float q_origin[3], q_cell[3], q_inv_cell[3];
     const DTri* tris;             // leaf order
     const pt_triangle* tri_ref;   // original order, reference layout (shading attributes)

@@ -338,7 +338,7 @@ constexpr int kLeafVote = PT_LEAFVOTE;
 constexpr int kExtendLds = PT_EXT_LDS;
 constexpr int kExtendBlocks = 256 * PT_EXT_BLOCKS_PER_CU;      // 256 CUs x the workgroups that fit one CU's LDS
 
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S, DCounters* ctr)
 {
     __shared__ uint2 s_stack[kExtendLds * kBlock];
@@ -350,7 +350,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     F3 o = f3(0.f, 0.f, 0.f), d = o, inv = o;
     // ray in grid coordinates for the compact nodes (uncounted build only)
     F3 oq = o, invq = o;
-    constexpr bool QUANT = !COUNT && PT_QUANT_NODES;
+    static_assert(!(COUNT && WIDE), "the counting build walks the binary tree the reference walks");
+    constexpr bool QUANT = !COUNT && (PT_QUANT_NODES || WIDE);
     Hit best; best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
     bool has_ray = false;
     bool more = true;
@@ -429,7 +430,10 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         }
         float4 n0 = ro4, n1 = ro4, n2 = ro4, n3 = ro4;
         if (descending) {
-            if (QUANT) {
+            if (WIDE) {
+                const float4* np = reinterpret_cast<const float4*>(S.nodes4 + cur);
+                n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
+            } else if (QUANT) {
                 const float4* np = reinterpret_cast<const float4*>(S.qnodes + cur);
                 n0 = np[0]; n1 = np[1];
             } else {
@@ -437,16 +441,51 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                 n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
             }
         }
-        float4 q0 = ro4, q1 = ro4, q2 = ro4;
+        float4 q0 = ro4, q1 = ro4, q2 = ro4, p0 = ro4, p1 = ro4, p2 = ro4;
         const DTri* tp = S.tris;
+        int leaf_count = 0;
         if (leaf_now) {
-            tp = S.tris + (~cur);
+            if (WIDE) { uint32_t enc = ~(uint32_t)cur; tp = S.tris + (enc & 0x3FFFFFFu); leaf_count = (int)(enc >> 26) + 1; }
+            else tp = S.tris + (~cur);
             q0 = tp[0].q0; q1 = tp[0].q1; q2 = tp[0].q2;
+            p0 = tp[1].q0; p1 = tp[1].q1; p2 = tp[1].q2;
         }
         asm volatile("" ::: "memory");      // loads stay above, their uses below
 
         // ---- one interior step for every descending lane
-        if (descending) {
+        if (descending && WIDE) {
+            // four children: entry distances on the quantized grid, culled against the best hit, then sorted
+            const uint32_t wd[12] = {__float_as_uint(n0.x), __float_as_uint(n0.y), __float_as_uint(n0.z), __float_as_uint(n0.w),
+                                     __float_as_uint(n1.x), __float_as_uint(n1.y), __float_as_uint(n1.z), __float_as_uint(n1.w),
+                                     __float_as_uint(n2.x), __float_as_uint(n2.y), __float_as_uint(n2.z), __float_as_uint(n2.w)};
+            int r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y), r2 = __float_as_int(n3.z), r3 = __float_as_int(n3.w);
+            float dk[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t a = wd[3 * k], b = wd[3 * k + 1], c = wd[3 * k + 2];
+                float t0x = ((float)(a & 0xffffu) - oq.x) * invq.x, t1x = ((float)(b >> 16) - oq.x) * invq.x;
+                float t0y = ((float)(a >> 16) - oq.y) * invq.y,    t1y = ((float)(c & 0xffffu) - oq.y) * invq.y;
+                float t0z = ((float)(b & 0xffffu) - oq.z) * invq.z, t1z = ((float)(c >> 16) - oq.z) * invq.z;
+                float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
+                float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+                dk[k] = (tf > tn && tf > 0.f && tn < best.t) ? tn : 1e30f;
+            }
+            float d0 = r0 == PT_TRAV_EMPTY ? 1e30f : dk[0], d1 = r1 == PT_TRAV_EMPTY ? 1e30f : dk[1];
+            float d2 = r2 == PT_TRAV_EMPTY ? 1e30f : dk[2], d3 = r3 == PT_TRAV_EMPTY ? 1e30f : dk[3];
+            auto cswap = [](float& da, int& ra, float& db, int& rb) {
+                bool sw = db < da;
+                float td = sw ? db : da; int tr = sw ? rb : ra;
+                db = sw ? da : db; rb = sw ? ra : rb;
+                da = td; ra = tr;
+            };
+            cswap(d0, r0, d1, r1); cswap(d2, r2, d3, r3); cswap(d0, r0, d2, r2); cswap(d1, r1, d3, r3); cswap(d1, r1, d2, r2);
+            if (d3 < 1e30f) push(r3, d3);
+            if (d2 < 1e30f) push(r2, d2);
+            if (d1 < 1e30f) push(r1, d1);
+            if (d0 < 1e30f) cur = r0;
+            else { cur = pop_valid(); if (cur == PT_TRAV_EMPTY) retire(); }
+        }
+        if (descending && !WIDE) {
             int left, right;
             float dl, dr;
             if (QUANT) {
@@ -476,17 +515,27 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         }
         // ---- leaf work for the lanes that waited at a leaf
         if (leaf_now) {
-            int count = __float_as_int(q1.w);
-            for (int i = 0;;) {
-                uint32_t id = __float_as_uint(q0.w);
+            const int count = WIDE ? leaf_count : __float_as_int(q1.w);
+            auto test = [&](const float4& a0, const float4& a1, const float4& a2) {
+                uint32_t id = __float_as_uint(a0.w);
                 float t, u, v;
                 if (COUNT) tl.tri += 1;
-                if (tri_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), o, d, best.t, t, u, v) &&
+                if (tri_test(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z), f3(a2.x, a2.y, a2.z), o, d, best.t, t, u, v) &&
                     !(best.tri != PT_NO_TRI && t == best.t && id > best.tri)) {
                     best.t = t; best.tri = id; best.u = u; best.v = v;
                 }
-                if (++i >= count) break;
-                q0 = tp[i].q0; q1 = tp[i].q1; q2 = tp[i].q2;
+            };
+            // records come two at a time (the second of the first pair was fetched with the first; the
+            // array has one record of padding, so reading one past a leaf is safe)
+            test(q0, q1, q2);
+            if (count > 1) {
+                test(p0, p1, p2);
+                for (int i = 2; i < count; i += 2) {
+                    q0 = tp[i].q0; q1 = tp[i].q1; q2 = tp[i].q2;
+                    p0 = tp[i + 1].q0; p1 = tp[i + 1].q1; p2 = tp[i + 1].q2;
+                    test(q0, q1, q2);
+                    if (i + 1 < count) test(p0, p1, p2);
+                }
             }
             cur = pop_valid();
             if (cur == PT_TRAV_EMPTY) retire();
@@ -504,7 +553,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                 inv = 1.0f / d;
                 if (COUNT) tl.box += 1;
                 float troot = box_entry(o, inv, S.root_min, S.root_max);
-                if (troot < best.t) cur = S.root_ref;
+                if (troot < best.t) cur = WIDE ? S.root_ref4 : S.root_ref;
                 if (QUANT) {
                     oq = (o - ld3(S.q_origin)) * ld3(S.q_inv_cell);
                     invq = inv * ld3(S.q_cell);
@@ -723,7 +772,8 @@ void launch_wf_trace(const WfParams& w, const DScene& S, const pt_ray* rays_dev,
     hipLaunchKernelGGL(wf_pack_rays_kernel, grid, block, 0, s, rays_dev, n, w.ray_o, w.ray_d, w.chunk_rays);
     hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, (int)grid.x);
     int ext_blocks = (int)grid.x < w.extend_blocks ? (int)grid.x : w.extend_blocks;
-    hipLaunchKernelGGL(wf_extend_kernel<false>, dim3(ext_blocks), block, 0, s, w, S, (DCounters*)nullptr);
+    if (S.wide) hipLaunchKernelGGL((wf_extend_kernel<false, true>), dim3(ext_blocks), block, 0, s, w, S, (DCounters*)nullptr);
+    else hipLaunchKernelGGL((wf_extend_kernel<false, false>), dim3(ext_blocks), block, 0, s, w, S, (DCounters*)nullptr);
     hipLaunchKernelGGL(wf_unpack_hits_kernel, grid, block, 0, s, w.hit, n, hits_dev);
 }
 
@@ -743,8 +793,9 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
     // persistent waves: enough workgroups to fill every CU, each pulls rays until the pool is drained
     int ext_blocks = (w.n_slots + kBlock - 1) / kBlock;
     if (ext_blocks > w.extend_blocks) ext_blocks = w.extend_blocks;
-    if (ctr) hipLaunchKernelGGL(wf_extend_kernel<true>, dim3(ext_blocks), block, 0, s, w, S, ctr);
-    else hipLaunchKernelGGL(wf_extend_kernel<false>, dim3(ext_blocks), block, 0, s, w, S, ctr);
+    if (ctr) hipLaunchKernelGGL((wf_extend_kernel<true, false>), dim3(ext_blocks), block, 0, s, w, S, ctr);
+    else if (S.wide) hipLaunchKernelGGL((wf_extend_kernel<false, true>), dim3(ext_blocks), block, 0, s, w, S, ctr);
+    else hipLaunchKernelGGL((wf_extend_kernel<false, false>), dim3(ext_blocks), block, 0, s, w, S, ctr);
     if (ext1) (void)hipEventRecord(ext1, s);
     if (ctr) {
         hipLaunchKernelGGL(wf_shade_kernel<true>, grid, block, 0, s, w, S, cam, ctr);

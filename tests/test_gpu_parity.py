@@ -244,9 +244,20 @@ def test_production_traversal_kernel_matches_brute_force():
     rays['o'][:, 1] = np.abs(rays['o'][:, 1]) * 0.8
     rays['d'][5] = [np.nan, 0, 1]; rays['o'][6] = [np.inf, 0, 0]; rays['d'][7] = [0, 0, 0]
     r = b.renderer(P)
-    fast = r.trace_closest_fast(rays)
     slow = r.trace_closest(rays)
+    fast = r.trace_closest_fast(rays)
     assert np.array_equal(fast['tri'], slow['tri']) and np.array_equal(bits(fast['t']), bits(slow['t']))
+    # the other node layouts of the same kernel: binary compact nodes, and wide leaves of up to 1 and 7 triangles
+    r.set_node_width(2)
+    alt = r.trace_closest_fast(rays)
+    assert np.array_equal(alt['tri'], slow['tri']) and np.array_equal(bits(alt['t']), bits(slow['t']))
+    for merge in (1, 7):
+        r.set_node_width(4, merge)
+        r.upload_scene(b.tris, b.mats, b.idx, b.nodes)
+        alt = r.trace_closest_fast(rays)
+        assert np.array_equal(alt['tri'], slow['tri']) and np.array_equal(bits(alt['t']), bits(slow['t'])), merge
+    r.set_node_width(4, 2)
+    r.upload_scene(b.tris, b.mats, b.idx, b.nodes)
     brute = orc.closest_brute(b.oracle(), rays[:3000])
     assert np.array_equal(fast['tri'][:3000], brute['tri']) and np.array_equal(bits(fast['t'][:3000]), bits(brute['t']))
     for n in (1, 63, 257):      # ragged sizes
