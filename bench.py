@@ -49,6 +49,7 @@ def main():
     ap.add_argument('--cpu-spp', type=int, default=12, help='frames the CPU oracle renders for the baseline (about 15 s on 16 cores)')
     ap.add_argument('--mode', choices=['wavefront', 'single_kernel'], default='wavefront')
     ap.add_argument('--pool', type=int, default=0, help='wavefront pool slots (0 = library default)')
+    ap.add_argument('--drain', type=int, default=-1, help='finish the last paths in one kernel once at most this many remain (-1 = library default, 0 = never)')
     ap.add_argument('--node-width', type=int, default=4, help='4-wide or binary (2) compact nodes in the traversal kernel')
     ap.add_argument('--tune', type=str, default='', help='refill_lanes,leaf_vote,blocks_per_cu for the traversal kernel')
     args = ap.parse_args()
@@ -83,6 +84,8 @@ def main():
     if args.pool:
         r.set_pool(args.pool, 64)
     r.set_node_width(args.node_width)
+    if args.drain >= 0:
+        r.set_drain(args.drain)
     if args.tune:
         r.set_extend_tuning(*[int(x) for x in args.tune.split(',')])
     stream = torch.cuda.current_stream()

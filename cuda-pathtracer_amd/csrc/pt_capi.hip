@@ -45,6 +45,7 @@ struct pt_ctx {
     DNode4* d_nodes4 = nullptr;
     bool wide_fits = false;
     int node_width = 4;
+    int drain_rays = 1 << 18;
     int leaf_merge = 2;
     DMat* d_mats = nullptr;
     DTex* d_tex = nullptr;
@@ -653,6 +654,13 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
                 for (int i = 0; i < batch; i++) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->st_ev[2 * i], c->st_ev[2 * i + 1]) == hipSuccess) { c->extend_ms += ms; c->extend_launches++; } }
             }
             if (c->wf_host_counters[WF_CTR_LIVE] == 0) break;
+            // all sample ids handed out and few paths left: finish them in one kernel instead of one stage
+            // launch sequence per remaining path vertex
+            if (c->drain_rays > 0 && c->wf_host_counters[WF_CTR_NEXT_SAMPLE] >= w.n_samples && c->wf_host_counters[WF_CTR_RAYS] <= (uint32_t)c->drain_rays) {
+                launch_wf_drain(w, c->scene, cam, ctr, c->stream);
+                HIP_TRY(hipGetLastError());
+                break;
+            }
         }
         launch_wf_accumulate(w, cam, c->accum, c->stream);
         HIP_TRY(hipGetLastError());
@@ -699,6 +707,13 @@ int pt_set_mode(pt_ctx* c, int mode)
 {
     if (!c || (mode != PT_MODE_WAVEFRONT && mode != PT_MODE_SINGLE_KERNEL)) { set_error("pt_set_mode: bad argument"); return PT_ERR_ARG; }
     c->mode = mode;
+    return PT_OK;
+}
+
+int pt_set_drain(pt_ctx* c, int max_rays)
+{
+    if (!c || max_rays < 0) { set_error("pt_set_drain: bad argument"); return PT_ERR_ARG; }
+    c->drain_rays = max_rays;
     return PT_OK;
 }
 

@@ -187,6 +187,9 @@ PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_
             if (total <= avail) {
                 s_plan[1] = total; s_plan[2] = 0;
                 next += total;
+            } else if (next >= w.n_samples) {
+                // every sample id has been handed out (the cursor was parked at n_samples): the slots retire
+                s_plan[1] = 0; s_plan[2] = w.n_samples;
             } else {
                 uint32_t c = atomicAdd(w.counters + WF_CTR_NEXT_SAMPLE, kSampleChunk);
                 s_plan[1] = avail; s_plan[2] = c;
@@ -574,7 +577,10 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
 
 // ---------------------------------------------------------------- shade
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void wf_shade_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+#ifndef PT_SHADE_WAVES
+#define PT_SHADE_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES))) void wf_shade_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
     uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= (uint32_t)w.n_slots) return;
@@ -642,7 +648,10 @@ __global__ __launch_bounds__(kBlock) void wf_shade_kernel(WfParams w, DScene S, 
 
 // ---------------------------------------------------------------- bsdf
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void wf_bsdf_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+#ifndef PT_BSDF_WAVES
+#define PT_BSDF_WAVES 4
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_BSDF_WAVES))) void wf_bsdf_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
     uint32_t count = w.bsdf_count[blockIdx.x];
     if (count == 0) return;                              // uniform over the workgroup
@@ -675,6 +684,72 @@ __global__ __launch_bounds__(kBlock) void wf_bsdf_kernel(WfParams w, DScene S, D
         uint32_t nr = block_count(active && P.state != ST_DONE);
         if (threadIdx.x == 0) w.chunk_rays[blockIdx.x] += nr;      // the shade launch wrote this block's count
     }
+    flush_tally<COUNT>(ctr, tl, nsamples);
+}
+
+// ---------------------------------------------------------------- drain
+// End of a render: every sample id has been handed out and few slots still carry a path. Another
+// hundred stage launches for the longest paths would cost their launch latencies in sequence; instead
+// each remaining slot runs its sample to the end in one kernel (the same state machine, one slot per
+// lane, reference-order traversal with the LDS stack). Workgroup b handles the b-th block of the list
+// of slot blocks that hold rays.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+{
+    if (blockIdx.x >= w.counters[WF_CTR_RAY_CHUNKS]) return;
+    uint32_t slot = w.chunk_list[blockIdx.x] * (uint32_t)kBlock + threadIdx.x;
+    float4 rd4 = w.ray_d[slot];
+    const bool live = __float_as_int(rd4.w) != 0;      // lanes without a path stay for the wave-wide tally
+    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Path P;
+    SampleId id;
+    P.state = ST_DONE;
+    if (live) {
+        load_core(w, slot, P, id);
+        load_light(w, slot, P);
+        float4 ro4 = w.ray_o[slot];
+        if (P.state == ST_SHADOW) {
+            load_vertex(w, slot, P);
+            P.so = f3(ro4.x, ro4.y, ro4.z); P.sd = f3(rd4.x, rd4.y, rd4.z);
+        }
+    }
+    // sample ids this workgroup still holds in its chunk (the global counter is exhausted, so nothing
+    // else will start them): lanes take them one by one as they become free
+    __shared__ uint32_t s_cur, s_end;
+    uint32_t* cw = w.block_chunk + 2 * (size_t)(slot / kBlock);
+    if (threadIdx.x == 0) { s_cur = cw[0]; s_end = cw[1] < w.n_samples ? cw[1] : w.n_samples; }
+    __syncthreads();
+    uint32_t nsamples = 0;
+    bool have = live;
+    for (;;) {
+        if (have) {
+            while (P.state != ST_DONE) {
+                if (P.state == ST_AFTER) { after_light<COUNT>(S, cam, P, tl); continue; }
+                bool shadow = P.state == ST_SHADOW;
+                F3 ro = shadow ? P.so : P.o;
+                F3 rd = shadow ? P.sd : P.d;
+                Hit h = closest_hit<kBlock, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
+                if (COUNT) tl.rays++;
+                Surf info;
+                resolve_hit<COUNT>(S, h, rd, info, tl.taps, tl.taps_r);
+                if (shadow) on_shadow_hit<COUNT>(S, cam, P, info, tl);
+                else on_path_hit<COUNT>(S, cam, P, info, tl);
+            }
+            float v = P.result * 3.f;
+            w.staging[id.stage_index] = v > 0.f ? v : 0.f;
+        }
+        uint32_t next = atomicAdd(&s_cur, 1u);
+        if (next >= s_end) break;
+        id = decode_sample(w, next);
+        begin_sample(P, cam, id.x, id.y, id.frame);
+        if (COUNT) nsamples++;
+        have = true;
+    }
+    w.ray_d[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+    P.state = ST_DONE;
+    store_core(w, slot, P, 0xFFFFFFFFu);
+    __syncthreads();
+    if (threadIdx.x == 0) { cw[0] = w.n_samples; cw[1] = w.n_samples; w.chunk_rays[slot / kBlock] = 0; }
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
 
@@ -804,6 +879,14 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
         hipLaunchKernelGGL(wf_shade_kernel<false>, grid, block, 0, s, w, S, cam, ctr);
         hipLaunchKernelGGL(wf_bsdf_kernel<false>, grid, block, 0, s, w, S, cam, ctr);
     }
+}
+
+void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s)
+{
+    dim3 grid((w.n_slots + kBlock - 1) / kBlock), block(kBlock);
+    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, w.n_slots / kBlock);
+    if (ctr) hipLaunchKernelGGL(wf_drain_kernel<true>, grid, block, 0, s, w, S, cam, ctr);
+    else hipLaunchKernelGGL(wf_drain_kernel<false>, grid, block, 0, s, w, S, cam, ctr);
 }
 
 void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, hipStream_t s)
