@@ -814,6 +814,28 @@ int pt_resolve_display(pt_ctx* c, int n_frames, uint8_t* rgba_out)
 
 int pt_save_png(const char* path, const uint8_t* rgba, int w, int h) { return save_png(path, rgba, w, h); }
 
+// The image as the reference's window shows it: pt_resolve_display followed by the post-process shader
+// (post_process.glsl:19-23) with the exposure / mult / saturation / gamma of params.
+int pt_resolve_display_post(pt_ctx* c, int n_frames, const pt_params* P, uint8_t* rgba_out)
+{
+    if (!c || !c->accum || n_frames <= 0 || !P) { set_error("pt_resolve_display_post: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    launch_resolve_display(c->accum, c->W * c->H, n_frames, c->display, c->stream);
+    float mult[3] = {P->mult.x, P->mult.y, P->mult.z};
+    launch_post_process(c->display, c->W * c->H, P->exposure, mult, P->saturation, P->gamma, c->display, c->stream);
+    HIP_TRY(hipGetLastError());
+    if (rgba_out) HIP_TRY(hipMemcpyAsync(rgba_out, c->display, (size_t)c->W * c->H * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return PT_OK;
+}
+
+int pt_save_pfm(const char* path, const float* rgb, int w, int h) { return save_pfm(path, rgb, w, h); }
+int pt_load_pfm(const char* path, float** rgb_out, int* w, int* h)
+{
+    if (!path || !rgb_out || !w || !h) { set_error("pt_load_pfm: bad argument"); return PT_ERR_ARG; }
+    return load_pfm(path, rgb_out, w, h);
+}
+
 int pt_trace_closest_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* hits_dev)
 {
     int rc = check_ready(c, false);

@@ -134,6 +134,30 @@ void launch_resolve_display(const float* accum_dev, int n_pixels, int n_frames, 
     hipLaunchKernelGGL(resolve_display_kernel, grid, block, 0, stream, accum_dev, n_pixels, (float)n_frames, rgba_dev);
 }
 
+// ---------------------------------------------------------------- display post-process
+// post_process.glsl:19-23 on the RGBA8 image the window would show: exposure, colour multiplier,
+// saturation about the Rec.709 luma, gamma; bytes are read as x/255 (texture fetch of an 8-bit
+// texture) and written as round(clamp(x) * 255) (framebuffer conversion).
+__global__ __launch_bounds__(256) void post_process_kernel(const uint8_t* __restrict__ in, int n_pixels, float exposure, float mx, float my, float mz, float saturation, float gamma,
+                                                           uint8_t* __restrict__ out)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pixels) return;
+    uchar4 p = reinterpret_cast<const uchar4*>(in)[i];
+    F3 col = f3((float)p.x / 255.0f, (float)p.y / 255.0f, (float)p.z / 255.0f);
+    col = col * exposure;
+    col = col * f3(mx, my, mz);
+    float lw = 0.2126f * col.x + 0.7152f * col.y + 0.0722f * col.z;
+    col = f3(lw * (1.0f - saturation) + col.x * saturation, lw * (1.0f - saturation) + col.y * saturation, lw * (1.0f - saturation) + col.z * saturation);
+    col = f3(pt_powf(col.x, gamma), pt_powf(col.y, gamma), pt_powf(col.z, gamma));
+    auto unorm = [](float v) -> uint8_t { if (!(v > 0.f)) return 0; if (v >= 1.f) return 255; return (uint8_t)(int)(v * 255.0f + 0.5f); };
+    reinterpret_cast<uchar4*>(out)[i] = make_uchar4(unorm(col.x), unorm(col.y), unorm(col.z), 255);
+}
+void launch_post_process(const uint8_t* in_dev, int n_pixels, float exposure, const float* mult3, float saturation, float gamma, uint8_t* out_dev, hipStream_t stream)
+{
+    hipLaunchKernelGGL(post_process_kernel, dim3((n_pixels + 255) / 256), dim3(256), 0, stream, in_dev, n_pixels, exposure, mult3[0], mult3[1], mult3[2], saturation, gamma, out_dev);
+}
+
 // ---------------------------------------------------------------- environment search tables
 // sampleEnvMap's binary searches (envmap_cuda.cu:28-57) compare against bilinearly filtered reads of
 // the CDF texture at fixed texel coordinates. Those reads depend only on the map, so they are

@@ -372,4 +372,43 @@ int save_png(const char* path, const uint8_t* rgba, int w, int h)
     return PT_OK;
 }
 
+// Portable float map, little endian, three channels, rows bottom-up as the format prescribes: lossless
+// storage of the fp32 accumulator (checkpoint / resume of a progressive render, HDR output).
+int save_pfm(const char* path, const float* rgb, int w, int h)
+{
+    if (!path || !rgb || w <= 0 || h <= 0) { set_error("save_pfm: bad argument"); return PT_ERR_ARG; }
+    FILE* f = fopen(path, "wb");
+    if (!f) { set_error("cannot write %s", path); return PT_ERR_IO; }
+    fprintf(f, "PF\n%d %d\n-1.0\n", w, h);
+    bool ok = true;
+    for (int y = h - 1; y >= 0 && ok; y--) ok = fwrite(rgb + (size_t)y * w * 3, sizeof(float), (size_t)w * 3, f) == (size_t)w * 3;
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { set_error("short write to %s", path); return PT_ERR_IO; }
+    return PT_OK;
+}
+
+int load_pfm(const char* path, float** rgb_out, int* w_out, int* h_out)
+{
+    *rgb_out = nullptr; *w_out = *h_out = 0;
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_error("cannot open %s", path); return PT_ERR_IO; }
+    char magic[3] = {0, 0, 0};
+    int w = 0, h = 0;
+    float scale = 0.f;
+    if (fscanf(f, "%2s %d %d %f", magic, &w, &h, &scale) != 4 || strcmp(magic, "PF") != 0 || w <= 0 || h <= 0 || (uint64_t)w * h > (1ull << 30) || !(scale < 0.f)) {
+        fclose(f); set_error("%s: not a little-endian three-channel PFM", path); return PT_ERR_IO;
+    }
+    if (fgetc(f) == EOF) { fclose(f); set_error("%s: truncated", path); return PT_ERR_IO; }       // the single whitespace after the header
+    float* px = (float*)malloc((size_t)w * h * 3 * sizeof(float));
+    if (!px) { fclose(f); set_error("out of memory"); return PT_ERR_NOMEM; }
+    for (int y = h - 1; y >= 0; y--) {
+        if (fread(px + (size_t)y * w * 3, sizeof(float), (size_t)w * 3, f) != (size_t)w * 3) { free(px); fclose(f); set_error("%s: pixel data truncated", path); return PT_ERR_IO; }
+    }
+    fclose(f);
+    float s = -scale;
+    if (s != 1.0f) for (size_t i = 0; i < (size_t)w * h * 3; i++) px[i] *= s;
+    *rgb_out = px; *w_out = w; *h_out = h;
+    return PT_OK;
+}
+
 } // namespace ptamd

@@ -20,7 +20,7 @@ EXPORTS = [
     'pt_last_error', 'pt_create', 'pt_destroy', 'pt_set_stream', 'pt_init', 'pt_clear_accum', 'pt_upload_triangles',
     'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_upload_texture', 'pt_upload_envmap',
     'pt_set_sky_mode', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
-    'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_trace_closest', 'pt_trace_closest_dev',
+    'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
     'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
     'pt_detmath_probe', 'pt_read_obj', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
     'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
@@ -129,6 +129,22 @@ def save_png(path, rgba):
     rgba = np.ascontiguousarray(rgba, dtype=np.uint8)
     h, w, _ = rgba.shape
     check(lib().pt_save_png(path.encode(), _p(rgba), C.c_int(w), C.c_int(h)))
+
+
+def save_pfm(path, rgb):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w, _ = rgb.shape
+    check(lib().pt_save_pfm(path.encode(), _p(rgb), C.c_int(w), C.c_int(h)))
+
+
+def load_pfm(path):
+    ptr, w, h = C.c_void_p(), C.c_int(), C.c_int()
+    check(lib().pt_load_pfm(path.encode(), C.byref(ptr), C.byref(w), C.byref(h)))
+    try:
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), (h.value, w.value, 3)).copy()
+    finally:
+        lib().pt_free(ptr)
+    return a
 
 
 # ------------------------------------------------------------------ device context
@@ -251,6 +267,12 @@ class Renderer:
         W, H = self.params.windowSize.x, self.params.windowSize.y
         out = np.zeros((H, W, 4), dtype=np.uint8)
         check(lib().pt_resolve_display(self.h, C.c_int(n_frames), _p(out)))
+        return out
+
+    def resolve_display_post(self, n_frames, params):
+        W, H = self.params.windowSize.x, self.params.windowSize.y
+        out = np.zeros((H, W, 4), dtype=np.uint8)
+        check(lib().pt_resolve_display_post(self.h, C.c_int(n_frames), C.byref(params), _p(out)))
         return out
 
     def trace_closest(self, rays, counted=False):

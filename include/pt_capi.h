@@ -184,6 +184,9 @@ int pt_write_accum(pt_ctx* ctx, const float* rgb);                      /* resto
 int pt_sync(pt_ctx* ctx);                                               /* wait for the context's stream; updates last_ms */
 int pt_resolve_display(pt_ctx* ctx, int n_frames, uint8_t* rgba_out);   /* accum/n -> AgX -> RGBA8 (pathtracer.cu:588-599); rgba_out may be NULL */
 int pt_save_png(const char* path, const uint8_t* rgba, int w, int h);   /* saveToFile, main.cpp:96-114 */
+int pt_resolve_display_post(pt_ctx* ctx, int n_frames, const pt_params* params, uint8_t* rgba_out); /* pt_resolve_display + the window's post-process shader, post_process.glsl:19-23 (exposure, mult, saturation, gamma of params) */
+int pt_save_pfm(const char* path, const float* rgb, int w, int h);       /* fp32 accumulator to a portable float map: checkpoint of a progressive render (the reference has none; it saves PNG only, main.cpp:96-114) */
+int pt_load_pfm(const char* path, float** rgb_out, int* w, int* h);      /* read it back (free with pt_free); feed pt_write_accum to resume */
 
 /* ---- closest-hit batch (test and measurement entry) ---- */
 int pt_trace_closest(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hits_out);

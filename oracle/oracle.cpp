@@ -1241,6 +1241,23 @@ void orc_resolve_display(const float* accum, int w, int h, int n_frames, uint8_t
     }
 }
 
+// post_process.glsl:19-23 applied to an RGBA8 image: exposure, multiplier, saturation about the luma, gamma;
+// texel = byte / 255, output byte = round(clamp(x) * 255) (the fixed-function conversions around the shader)
+void orc_post_process(const uint8_t* in, int w, int h, const pt_params* P, uint8_t* out)
+{
+    auto unorm = [](float v) -> uint8_t { if (!(v > 0.f)) return 0; if (v >= 1.f) return 255; return (uint8_t)(int)(v * 255.0f + 0.5f); };
+    for (int i = 0; i < w * h; i++) {
+        V3 col = mk((float)in[4 * i] / 255.0f, (float)in[4 * i + 1] / 255.0f, (float)in[4 * i + 2] / 255.0f);
+        col = col * P->exposure;
+        col = col * from(P->mult);
+        float lw = 0.2126f * col.x + 0.7152f * col.y + 0.0722f * col.z;
+        float s = P->saturation;
+        col = mk(lw * (1.0f - s) + col.x * s, lw * (1.0f - s) + col.y * s, lw * (1.0f - s) + col.z * s);      // mix(vec3(lw), col, s)
+        col = mk(pt_powf(col.x, P->gamma), pt_powf(col.y, P->gamma), pt_powf(col.z, P->gamma));
+        out[4 * i] = unorm(col.x); out[4 * i + 1] = unorm(col.y); out[4 * i + 2] = unorm(col.z); out[4 * i + 3] = 255;
+    }
+}
+
 void orc_agx(const float in[3], float out[3])
 {
     V3 c = agx_tonemap(mk(in[0], in[1], in[2]));

@@ -175,6 +175,14 @@ def resolve_display(accum, n_frames):
     return out
 
 
+def post_process(rgba, params):
+    rgba = np.ascontiguousarray(rgba, np.uint8)
+    H, W, _ = rgba.shape
+    out = np.zeros_like(rgba)
+    lib().orc_post_process(_p(rgba), C.c_int(W), C.c_int(H), C.byref(params), _p(out))
+    return out
+
+
 def agx(rgb):
     i = (C.c_float * 3)(*[float(x) for x in rgb])
     o = (C.c_float * 3)()

@@ -236,6 +236,24 @@ def test_png_writer_round_trip(tmp_path):
     assert np.array_equal(np.asarray(Image.open(p)), img)
 
 
+def test_pfm_round_trip_is_lossless(tmp_path):
+    rng = np.random.default_rng(6)
+    img = rng.normal(0, 100, (7, 11, 3)).astype(np.float32)
+    img[0, 0] = [np.inf, -0.0, 1e-42]
+    p = os.path.join(str(tmp_path), 'accum.pfm')
+    lib.save_pfm(p, img)
+    raw = open(p, 'rb').read()
+    assert raw.startswith(b'PF\n11 7\n-1.0\n') and len(raw) == len(b'PF\n11 7\n-1.0\n') + 7 * 11 * 12
+    # rows are stored bottom-up
+    assert np.array_equal(np.frombuffer(raw[-11 * 12:], '<f4').view(np.uint32), bits(img[0]).ravel())
+    back = lib.load_pfm(p)
+    assert np.array_equal(bits(back), bits(img))
+    with open(p, 'wb') as f:
+        f.write(b'PF\n11 7\n1.0\n' + b'\0' * 10)
+    with pytest.raises(ptamd.PtError):
+        lib.load_pfm(p)
+
+
 # ------------------------------------------------------------------ BVH builder
 @pytest.mark.parametrize('n,seed', [(1, 1), (2, 2), (3, 3), (37, 4), (500, 5), (3000, 6)])
 def test_host_builder_reproduces_the_reference_builder(n, seed):
@@ -316,6 +334,7 @@ def _gloo_worker(rank, world, port, out_dir):
     os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     try:
+        util.SCRATCH = os.path.join(out_dir, 'rank%d' % rank)       # each rank writes its own copy of the scene files
         b = util.cornell('sky')
         P = scenes.cornell_params(ptamd.default_params(20, 20))
         S = b.oracle(P)
@@ -342,7 +361,6 @@ def test_two_rank_sample_partition_with_gloo_reduce(tmp_path):
     import socket
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
-    util.cornell('sky')         # generate the scene files before the workers race for them
     mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     err, byte_diff, total = np.load(os.path.join(str(tmp_path), 'result.npy'))
     assert total > 0 and err <= 1e-4 and byte_diff <= 1

@@ -249,6 +249,28 @@ def test_agx_tonemap_properties():
     assert np.array_equal(img[0, 1], orc.resolve_display(acc / 4, 1)[0, 1])
 
 
+def test_post_process_shader_restatement():
+    """post_process.glsl:19-23: with the application defaults (all factors 1) the image passes through unchanged;
+    otherwise exposure and multiplier scale, saturation 0 gives the Rec.709 luma, gamma is a power."""
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (5, 9, 4), dtype=np.uint8); img[..., 3] = 255
+    P = ptamd.default_params(9, 5)
+    assert np.array_equal(orc.post_process(img, P), img)
+    P.exposure = 0.5
+    half = orc.post_process(img, P)
+    assert np.all(np.abs(half[..., :3].astype(int) - np.round(img[..., :3] / 2.0)) <= 1)
+    P.exposure = 1.0; P.saturation = 0.0
+    grey = orc.post_process(img, P)
+    lum = img[..., 0] * 0.2126 + img[..., 1] * 0.7152 + img[..., 2] * 0.0722
+    assert np.all(np.ptp(grey[..., :3].astype(int), axis=-1) == 0) and np.all(np.abs(grey[..., 0] - lum) <= 1)
+    P.saturation = 1.0; P.gamma = 2.0
+    sq = orc.post_process(img, P)
+    assert np.all(np.abs(sq[..., :3] - (img[..., :3] / 255.0) ** 2 * 255) <= 1)
+    P.gamma = 1.0; P.mult = ptamd.Float3(2.0, 0.0, 1.0)
+    m = orc.post_process(img, P)
+    assert np.all(m[..., 1] == 0) and np.array_equal(m[..., 2], img[..., 2]) and np.all(m[..., 0] == np.minimum(img[..., 0].astype(int) * 2, 255))
+
+
 def test_camera_basis_matches_product_host_code():
     """pathtracer.cu:568-571 (the rotation of rayDirectionZ by cameraAngle and the derived uu, vv)."""
     P = ptamd.default_params(64, 48)

@@ -323,3 +323,29 @@ def test_full_size_render_properties():
             rgb, _ = orc.pixel_sample(S, P, int(x), int(y), f, 512)
             acc = acc + rgb
         assert np.array_equal(bits(acc), bits(wave[y, x])), (x, y)
+
+
+def test_post_process_and_checkpoint_resume(tmp_path):
+    """The window's post-process stage matches its restatement byte for byte, and a render resumed from a saved
+    accumulator (PFM) equals the uninterrupted one."""
+    import os
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(40, 24))
+    r = b.renderer(P)
+    r.set_max_bounces(6)
+    r.render(P, 0, 6)
+    whole = r.read_accum()
+    P.exposure = 1.3; P.gamma = 0.8; P.saturation = 1.25; P.mult = ptamd.Float3(1.0, 0.9, 0.8)
+    img = r.resolve_display_post(6, P)
+    assert np.array_equal(img, orc.post_process(orc.resolve_display(whole, 6), P))
+    r.clear_accum()
+    r.render(P, 0, 2)
+    path = os.path.join(str(tmp_path), 'ckpt.pfm')
+    lib.save_pfm(path, r.read_accum())
+    r.close()
+    r2 = b.renderer(P)
+    r2.set_max_bounces(6)
+    r2.write_accum(lib.load_pfm(path))
+    r2.render(P, 2, 6)
+    assert np.array_equal(bits(r2.read_accum()), bits(whole))
+    r2.close()
