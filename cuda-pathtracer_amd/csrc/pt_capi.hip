@@ -829,6 +829,11 @@ int pt_resolve_display_post(pt_ctx* c, int n_frames, const pt_params* P, uint8_t
     return PT_OK;
 }
 
+int pt_load_texture_png(const char* path, int comps, float** texels_out, int* w, int* h)
+{
+    if (!path || !texels_out || !w || !h) { set_error("pt_load_texture_png: bad argument"); return PT_ERR_ARG; }
+    return load_png_texture(path, comps, texels_out, w, h);
+}
 int pt_save_pfm(const char* path, const float* rgb, int w, int h) { return save_pfm(path, rgb, w, h); }
 int pt_load_pfm(const char* path, float** rgb_out, int* w, int* h)
 {

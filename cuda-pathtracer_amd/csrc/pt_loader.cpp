@@ -372,6 +372,95 @@ int save_png(const char* path, const uint8_t* rgba, int w, int h)
     return PT_OK;
 }
 
+// ---------------------------------------------------------------- PNG decode -> texture texels
+// What genTexture / genTexture_float hand to the device (image_loader.h:5-30,49-72): the image read as 8-bit
+// RGBA, rows flipped (row y of the array is image row h-1-y), values / 255, four channels or the red channel
+// alone. The reference decodes through sf::Image; here a PNG reader on zlib: bit depths 8 and 16 (the high
+// byte), colour types grey, RGB, palette, grey+alpha, RGBA, non-interlaced.
+namespace {
+inline uint32_t be32(const uint8_t* p) { return (uint32_t)p[0] << 24 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 8 | p[3]; }
+inline int paeth(int a, int b, int c) { int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c); return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c); }
+}
+
+int load_png_texture(const char* path, int comps, float** texels_out, int* w_out, int* h_out)
+{
+    *texels_out = nullptr; *w_out = *h_out = 0;
+    if (comps != 1 && comps != 4) { set_error("load_png_texture: comps must be 1 or 4"); return PT_ERR_ARG; }
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_error("cannot open %s", path); return PT_ERR_IO; }
+    std::vector<uint8_t> file;
+    {
+        uint8_t buf[65536]; size_t n;
+        while ((n = fread(buf, 1, sizeof(buf), f)) > 0) file.insert(file.end(), buf, buf + n);
+        fclose(f);
+    }
+    static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    if (file.size() < 8 || memcmp(file.data(), sig, 8) != 0) { set_error("%s: not a PNG file", path); return PT_ERR_IO; }
+    uint32_t w = 0, h = 0; int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, plte, trns;
+    bool have_ihdr = false, have_end = false;
+    for (size_t pos = 8; pos + 12 <= file.size();) {
+        uint32_t len = be32(&file[pos]);
+        if ((uint64_t)pos + 12 + len > file.size()) { set_error("%s: truncated chunk", path); return PT_ERR_IO; }
+        const uint8_t* type = &file[pos + 4];
+        const uint8_t* body = &file[pos + 8];
+        if (be32(body + len) != (uint32_t)crc32(crc32(0L, Z_NULL, 0), type, len + 4)) { set_error("%s: chunk checksum mismatch", path); return PT_ERR_IO; }
+        if (!memcmp(type, "IHDR", 4) && len >= 13) {
+            w = be32(body); h = be32(body + 4); depth = body[8]; ctype = body[9]; interlace = body[12]; have_ihdr = true;
+        } else if (!memcmp(type, "PLTE", 4)) plte.assign(body, body + len);
+        else if (!memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
+        else if (!memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
+        else if (!memcmp(type, "IEND", 4)) { have_end = true; break; }
+        pos += 12 + (size_t)len;
+    }
+    if (!have_ihdr || !have_end || w == 0 || h == 0 || (uint64_t)w * h > (1ull << 28)) { set_error("%s: bad PNG header", path); return PT_ERR_IO; }
+    int channels = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (channels == 0 || interlace != 0 || !(depth == 8 || (depth == 16 && ctype != 3) || (ctype == 3 && (depth == 1 || depth == 2 || depth == 4)) || (ctype == 0 && (depth == 1 || depth == 2 || depth == 4)))) {
+        set_error("%s: unsupported PNG (colour type %d, depth %d, interlace %d)", path, ctype, depth, interlace); return PT_ERR_IO;
+    }
+    size_t bpp_bits = (size_t)channels * depth, stride = ((size_t)w * bpp_bits + 7) / 8, bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;
+    std::vector<uint8_t> raw((stride + 1) * h);
+    uLongf out_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &out_len, idat.data(), (uLong)idat.size()) != Z_OK || out_len != raw.size()) { set_error("%s: bad image data", path); return PT_ERR_IO; }
+    std::vector<uint8_t> prev(stride, 0), cur(stride);
+    float* px = (float*)malloc((size_t)w * h * comps * sizeof(float));
+    if (!px) { set_error("out of memory"); return PT_ERR_NOMEM; }
+    for (uint32_t y = 0; y < h; y++) {
+        const uint8_t* line = &raw[(stride + 1) * y];
+        int filter = line[0];
+        for (size_t i = 0; i < stride; i++) {
+            int a = i >= bpp ? cur[i - bpp] : 0, b = prev[i], c = i >= bpp ? prev[i - bpp] : 0, x = line[1 + i];
+            int v = filter == 0 ? x : filter == 1 ? x + a : filter == 2 ? x + b : filter == 3 ? x + ((a + b) >> 1) : filter == 4 ? x + paeth(a, b, c) : -1;
+            if (v < 0) { free(px); set_error("%s: bad row filter", path); return PT_ERR_IO; }
+            cur[i] = (uint8_t)v;
+        }
+        float* dst = px + (size_t)(h - 1 - y) * w * comps;          // image_loader.h:15: rows flipped
+        for (uint32_t x = 0; x < w; x++) {
+            uint8_t r, g, b, a = 255;
+            auto sample = [&](int ch) -> uint8_t {      // 8 most significant bits of channel ch of pixel x
+                if (depth == 16) return cur[((size_t)x * channels + ch) * 2];
+                if (depth == 8) return cur[(size_t)x * channels + ch];
+                size_t bit = (size_t)x * depth; int v = (cur[bit >> 3] >> (8 - depth - (int)(bit & 7))) & ((1 << depth) - 1);
+                return ctype == 3 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1));
+            };
+            if (ctype == 3) {
+                size_t k = sample(0);
+                if (3 * k + 2 >= plte.size()) { r = g = b = 0; }
+                else { r = plte[3 * k]; g = plte[3 * k + 1]; b = plte[3 * k + 2]; }
+                if (k < trns.size()) a = trns[k];
+            } else if (ctype == 0) { r = g = b = sample(0); }
+            else if (ctype == 4) { r = g = b = sample(0); a = sample(1); }
+            else if (ctype == 2) { r = sample(0); g = sample(1); b = sample(2); }
+            else { r = sample(0); g = sample(1); b = sample(2); a = sample(3); }
+            if (comps == 4) { dst[4 * x] = (float)r / 255.0f; dst[4 * x + 1] = (float)g / 255.0f; dst[4 * x + 2] = (float)b / 255.0f; dst[4 * x + 3] = (float)a / 255.0f; }
+            else dst[x] = (float)r / 255.0f;
+        }
+        prev.swap(cur);
+    }
+    *texels_out = px; *w_out = (int)w; *h_out = (int)h;
+    return PT_OK;
+}
+
 // Portable float map, little endian, three channels, rows bottom-up as the format prescribes: lossless
 // storage of the fp32 accumulator (checkpoint / resume of a progressive render, HDR output).
 int save_pfm(const char* path, const float* rgb, int w, int h)

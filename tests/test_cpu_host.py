@@ -65,6 +65,27 @@ def test_no_gpu_means_an_error_not_a_fallback():
         ptamd.Renderer(0)
 
 
+def test_headless_front_end_reports_errors(tmp_path):
+    """ptamd_render is written against the C-ABI only; it must stop with the library's message, not fall back."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, 'cuda-pathtracer_amd', 'ptamd_render')
+    assert os.path.exists(exe), 'build it with make -C cuda-pathtracer_amd'
+    r = subprocess.run([exe, '--obj', '/nonexistent.obj', '--dir', '/tmp/', '--hdr', 'x.hdr'], capture_output=True, text=True)
+    assert r.returncode == 1 and 'cannot open model' in r.stderr
+    assert subprocess.run([exe], capture_output=True).returncode == 2
+    if not torch.cuda.is_available():
+        util.SCRATCH = str(tmp_path)
+        try:
+            obj = scenes.cornell(os.path.join(str(tmp_path), 'cornell'))
+        finally:
+            util.SCRATCH = os.path.join(ROOT, 'tests', '_scratch')
+        d = os.path.dirname(obj)
+        r = subprocess.run([exe, '--obj', obj, '--dir', d + '/', '--hdr', os.path.join(d, 'black_4x2.hdr'), '--size', '16x16', '--spp', '1',
+                            '--out', os.path.join(str(tmp_path), 'o.png')], capture_output=True, text=True)
+        assert r.returncode == 1 and 'opening the GPU' in r.stderr and not os.path.exists(os.path.join(str(tmp_path), 'o.png'))
+
+
 # ------------------------------------------------------------------ OBJ / MTL
 def _write(path, text):
     with open(path, 'w') as f:
@@ -234,6 +255,38 @@ def test_png_writer_round_trip(tmp_path):
     assert np.array_equal(_decode_png(p), img)
     from PIL import Image
     assert np.array_equal(np.asarray(Image.open(p)), img)
+
+
+def test_png_texture_decoder_matches_an_independent_decoder(tmp_path):
+    """genTexture / genTexture_float (image_loader.h:5-89): RGBA8 view of the file, rows flipped, / 255."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    d = str(tmp_path)
+    for mode, (w, h) in (('L', (13, 7)), ('RGB', (16, 9)), ('RGBA', (5, 5)), ('LA', (8, 3)), ('P', (12, 12)), ('1', (17, 5))):
+        if mode == '1':
+            img = Image.fromarray((rng.integers(0, 2, (h, w)) * 255).astype(np.uint8)).convert('1')
+        elif mode == 'P':
+            img = Image.fromarray(rng.integers(0, 256, (h, w, 3), dtype=np.uint8)).convert('P')
+        else:
+            ch = {'L': 1, 'RGB': 3, 'RGBA': 4, 'LA': 2}[mode]
+            a = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+            img = Image.fromarray(a[:, :, 0] if ch == 1 else a, mode)
+        p = os.path.join(d, mode + '.png')
+        img.save(p)
+        for comps in (4, 1):
+            got = lib.load_texture_png(p, comps)
+            assert got.shape == (h, w, comps) and np.array_equal(got, scenes.decode_texture(p, comps)), (mode, comps)
+    bad = os.path.join(d, 'bad.png')
+    raw = bytearray(open(os.path.join(d, 'RGB.png'), 'rb').read())
+    raw[40] ^= 0xff
+    open(bad, 'wb').write(bytes(raw))
+    with pytest.raises(ptamd.PtError):
+        lib.load_texture_png(bad, 4)
+    with pytest.raises(ptamd.PtError):
+        lib.load_texture_png(os.path.join(d, 'missing.png'), 4)
+    import glob
+    for p in sorted(glob.glob('/root/reference/Cuda Pathtracer/assets/models/**/*.png', recursive=True))[:6]:      # the textures the reference ships
+        assert np.array_equal(lib.load_texture_png(p, 4), scenes.decode_texture(p, 4)), p
 
 
 def test_pfm_round_trip_is_lossless(tmp_path):

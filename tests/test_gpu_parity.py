@@ -349,3 +349,32 @@ def test_post_process_and_checkpoint_resume(tmp_path):
     r2.render(P, 2, 6)
     assert np.array_equal(bits(r2.read_accum()), bits(whole))
     r2.close()
+
+
+def test_headless_front_end_end_to_end(tmp_path):
+    """ptamd_render (C++ on the C-ABI: model, textures, BVH, environment, frames, PNG) against the oracle on the
+    atrium with its texture maps, in one headless call and in per-frame calls with a checkpoint in between."""
+    import os
+    import subprocess
+    exe = os.path.join(util.ROOT, 'cuda-pathtracer_amd', 'ptamd_render')
+    b = util.atrium(detail=0.2, env_size=(64, 32))
+    d = os.path.join(util.SCRATCH, 'atrium_0.2_0_0')
+    P = scenes.atrium_params(ptamd.default_params(48, 32))
+    want, _ = orc.render(b.oracle(P), P, 0, 4, 16)
+    o, a = P.rayOrigin, P.cameraAngle
+    common = [exe, '--obj', os.path.join(d, 'atrium.obj'), '--dir', d + '/', '--hdr', os.path.join(d, 'sky.hdr'), '--size', '48x32', '--bounces', '16',
+              '--origin', '%r,%r,%r' % (o.x, o.y, o.z), '--angle', '%r,%r' % (a.x, a.y), '--fov', repr(P.fov)]
+    png, pfm = os.path.join(str(tmp_path), 'a.png'), os.path.join(str(tmp_path), 'a.pfm')
+    r = subprocess.run(common + ['--spp', '4', '--out', png, '--pfm', pfm], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(bits(lib.load_pfm(pfm)), bits(want))
+    from PIL import Image
+    assert np.array_equal(np.asarray(Image.open(png)), orc.resolve_display(want, 4))
+    # two frames per-frame like the application, checkpoint, two more frames resumed
+    ck = os.path.join(str(tmp_path), 'ck.pfm')
+    r = subprocess.run(common + ['--spp', '2', '--frames-per-call', '1', '--out', png, '--pfm', ck], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(common + ['--spp', '2', '--resume', ck, '--resume-frames', '2', '--out', png, '--pfm', pfm], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert np.array_equal(bits(lib.load_pfm(pfm)), bits(want))
+    assert np.array_equal(np.asarray(Image.open(png)), orc.resolve_display(want, 4))
