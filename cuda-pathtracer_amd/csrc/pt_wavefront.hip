@@ -332,6 +332,9 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
 #ifndef PT_QUANT_NODES
 #define PT_QUANT_NODES 1   // production traversal reads the 32-byte compact nodes
 #endif
+#ifndef PT_BOX_FMA
+#define PT_BOX_FMA 1
+#endif
 #ifndef PT_STAMPS
 #define PT_STAMPS 0      // diagnostic build: per-section cycle stamps in the extend kernel
 #endif
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     uint32_t slot = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = o, inv = o;
     // ray in grid coordinates for the compact nodes (uncounted build only)
-    F3 oq = o, invq = o;
+    F3 oq = o, invq = o, noq = o;
     static_assert(!(COUNT && WIDE), "the counting build walks the binary tree the reference walks");
     constexpr bool QUANT = !COUNT && (PT_QUANT_NODES || WIDE);
     Hit best; best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
@@ -466,9 +469,17 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t a = wd[3 * k], b = wd[3 * k + 1], c = wd[3 * k + 2];
+#if PT_BOX_FMA
+                // plane distances as q * inv - o * inv in one fused operation each; an axis the ray is parallel to
+                // gives inf - inf = NaN on both planes, which min/max ignore: the box only gets more conservative
+                float t0x = __builtin_fmaf((float)(a & 0xffffu), invq.x, noq.x), t1x = __builtin_fmaf((float)(b >> 16), invq.x, noq.x);
+                float t0y = __builtin_fmaf((float)(a >> 16), invq.y, noq.y),    t1y = __builtin_fmaf((float)(c & 0xffffu), invq.y, noq.y);
+                float t0z = __builtin_fmaf((float)(b & 0xffffu), invq.z, noq.z), t1z = __builtin_fmaf((float)(c >> 16), invq.z, noq.z);
+#else
                 float t0x = ((float)(a & 0xffffu) - oq.x) * invq.x, t1x = ((float)(b >> 16) - oq.x) * invq.x;
                 float t0y = ((float)(a >> 16) - oq.y) * invq.y,    t1y = ((float)(c & 0xffffu) - oq.y) * invq.y;
                 float t0z = ((float)(b & 0xffffu) - oq.z) * invq.z, t1z = ((float)(c >> 16) - oq.z) * invq.z;
+#endif
                 float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
                 float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
                 dk[k] = (tf > tn && tf > 0.f && tn < best.t) ? tn : 1e30f;
@@ -560,6 +571,14 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                 if (QUANT) {
                     oq = (o - ld3(S.q_origin)) * ld3(S.q_inv_cell);
                     invq = inv * ld3(S.q_cell);
+#if PT_BOX_FMA
+                    // an axis the ray is parallel to: a huge finite slope keeps q * inv - o * inv free of inf - inf and
+                    // still puts both planes of a slab the origin is outside of on the same side (boxes carry two
+                    // cells of padding, far more than the rounding of the products)
+                    invq = f3(__builtin_fminf(__builtin_fmaxf(invq.x, -1e30f), 1e30f), __builtin_fminf(__builtin_fmaxf(invq.y, -1e30f), 1e30f),
+                              __builtin_fminf(__builtin_fmaxf(invq.z, -1e30f), 1e30f));
+#endif
+                    noq = f3(-(oq.x * invq.x), -(oq.y * invq.y), -(oq.z * invq.z));
                 }
             }
             if (cur == PT_TRAV_EMPTY) retire();

@@ -242,6 +242,13 @@ def test_production_traversal_kernel_matches_brute_force():
     P = scenes.atrium_params(ptamd.default_params(64, 64))
     rays = scenes.random_rays(300000, seed=15, extent=1400.0)
     rays['o'][:, 1] = np.abs(rays['o'][:, 1]) * 0.8
+    # axis-parallel and almost parallel directions (zero, negative zero and denormal components)
+    k = np.arange(len(rays))
+    for a in range(3):
+        rays['d'][k % 11 == a, a] = 0.0
+        rays['d'][k % 11 == a + 3, a] = 1e-41
+    rays['d'][k % 11 == 6] = [0.0, -1.0, -0.0]
+    rays['d'] /= np.maximum(np.linalg.norm(rays['d'], axis=1, keepdims=True), 1e-30)
     rays['d'][5] = [np.nan, 0, 1]; rays['o'][6] = [np.inf, 0, 0]; rays['d'][7] = [0, 0, 0]
     r = b.renderer(P)
     slow = r.trace_closest(rays)

@@ -17,3 +17,16 @@ for name, b, ext in (('atrium', util.atrium(detail=0.5), 1400.0), ('soup', util.
         print(name, 'width', width, 'hits', int((slow['tri'] != 0xFFFFFFFF).sum()), 'mismatches', bad, 'ms', r.counters()['last_ms'])
     r.close()
 print('total mismatches', tot)
+# axis-parallel and nearly parallel rays (zero and denormal direction components)
+b = util.atrium(detail=0.5)
+r = b.renderer(ptamd.default_params(64, 64))
+rays = scenes.random_rays(600000, seed=10, extent=1400.0)
+k = np.arange(len(rays))
+for a in range(3):
+    rays['d'][k % 7 == a, a] = 0.0
+    rays['d'][k % 7 == a + 3, a] = 1e-41
+rays['d'][k % 7 == 6] = [0.0, -1.0, -0.0]
+n = np.linalg.norm(rays['d'], axis=1, keepdims=True); rays['d'] /= np.maximum(n, 1e-30)
+slow = r.trace_closest(rays); fast = r.trace_closest_fast(rays)
+bad = int((fast['tri'] != slow['tri']).sum() + (bits(fast['t']) != bits(slow['t'])).sum())
+print('axis-parallel rays: hits', int((slow['tri'] != 0xFFFFFFFF).sum()), 'mismatches', bad, 'ms', r.counters()['last_ms'])
