@@ -49,6 +49,7 @@ def main():
     ap.add_argument('--cpu-spp', type=int, default=12, help='frames the CPU oracle renders for the baseline (about 15 s on 16 cores)')
     ap.add_argument('--mode', choices=['wavefront', 'single_kernel'], default='wavefront')
     ap.add_argument('--pool', type=int, default=0, help='wavefront pool slots (0 = library default)')
+    ap.add_argument('--fp32-textures', action='store_true', help='keep 8-bit textures as fp32 texels instead of bytes')
     ap.add_argument('--drain', type=int, default=-1, help='finish the last paths in one kernel once at most this many remain (-1 = library default, 0 = never)')
     ap.add_argument('--node-width', type=int, default=4, help='4-wide or binary (2) compact nodes in the traversal kernel')
     ap.add_argument('--tune', type=str, default='', help='refill_lanes,leaf_vote,blocks_per_cu for the traversal kernel')
@@ -78,7 +79,7 @@ def main():
     util.SCRATCH = os.path.join(ROOT, 'tests', '_scratch', 'rank%d' % rank)
     bundle = util.atrium(detail=detail)
     P = scenes.atrium_params(ptamd.default_params(W, H))
-    r = bundle.renderer(P, local_rank)
+    r = bundle.renderer(P, local_rank, pack_textures=not args.fp32_textures)
     r.set_max_bounces(args.bounces)
     r.set_mode(0 if args.mode == 'wavefront' else 1)
     if args.pool:

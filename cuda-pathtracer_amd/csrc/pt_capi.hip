@@ -50,7 +50,8 @@ struct pt_ctx {
     DMat* d_mats = nullptr;
     DTex* d_tex = nullptr;
     std::vector<DTex> tex_table;
-    std::vector<float*> tex_data;
+    std::vector<void*> tex_data;
+    bool pack_textures = true;
     float* d_env = nullptr;
     float* d_cdf = nullptr;
     float* d_env_tables = nullptr;   // row table [H] followed by column table [H*W]
@@ -129,7 +130,7 @@ void pt_destroy(pt_ctx* c)
     if (c->d_tri_ref) (void)hipFree(c->d_tri_ref);
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_tex) (void)hipFree(c->d_tex);
-    for (float* p : c->tex_data) (void)hipFree(p);
+    for (void* p : c->tex_data) (void)hipFree(p);
     for (hipEvent_t e : c->st_ev) if (e) (void)hipEventDestroy(e);
     if (c->d_env) (void)hipFree(c->d_env);
     if (c->d_cdf) (void)hipFree(c->d_cdf);
@@ -465,14 +466,51 @@ int pt_upload_texture(pt_ctx* c, const float* texels, int w, int h, int comps, u
 {
     if (!c || !texels || !handle_out || w <= 0 || h <= 0 || (comps != 1 && comps != 4)) { set_error("pt_upload_texture: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
-    float* d = nullptr;
-    size_t bytes = (size_t)w * h * comps * sizeof(float);
-    HIP_TRY(hipMalloc((void**)&d, bytes));
-    HIP_TRY(hipMemcpy(d, texels, bytes, hipMemcpyHostToDevice));
+    // 8-bit image data (every value exactly k/255) is kept as bytes: the sampler rebuilds the same floats
+    size_t n = (size_t)w * h * comps;
+    std::vector<uint8_t> packed;
+    bool bytes_ok = c->pack_textures;
+    if (bytes_ok) {
+        packed.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            float v = texels[i];
+            if (!(v >= 0.f && v <= 1.f)) { bytes_ok = false; break; }
+            int k = (int)(v * 255.0f + 0.5f);
+            float back = (float)k / 255.0f;
+            if (memcmp(&back, &v, sizeof(float)) != 0) { bytes_ok = false; break; }       // bit equality: -0 stays a float texture
+            packed[i] = (uint8_t)k;
+        }
+    }
+    void* d = nullptr;
+    size_t bytes = bytes_ok ? n : n * sizeof(float);
+    HIP_TRY(hipMalloc(&d, bytes));
+    HIP_TRY(hipMemcpy(d, bytes_ok ? (const void*)packed.data() : (const void*)texels, bytes, hipMemcpyHostToDevice));
     c->tex_data.push_back(d);
-    DTex t; t.texels = d; t.w = w; t.h = h; t.comps = comps; t.pad = 0;
+    DTex t; t.texels = d; t.w = w; t.h = h; t.comps = comps; t.format = bytes_ok ? 1 : 0;
     c->tex_table.push_back(t);
     *handle_out = (uint64_t)c->tex_table.size();
+    return PT_OK;
+}
+
+int pt_set_texture_packing(pt_ctx* c, int on)
+{
+    if (!c) { set_error("null context"); return PT_ERR_ARG; }
+    c->pack_textures = on != 0;
+    return PT_OK;
+}
+
+// device evaluation of the byte -> float conversion of packed textures, all 256 values
+int pt_unorm8_probe(pt_ctx* c, float* out256)
+{
+    if (!c || !out256) { set_error("pt_unorm8_probe: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    float* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, 256 * sizeof(float)));
+    launch_unorm8_probe(d, c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out256, d, 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipFree(d);
     return PT_OK;
 }
 

@@ -155,6 +155,38 @@ PT_DEV float tex1(const float* texels, int w, int h, float u, float v)
     Taps t = tex_taps(w, h, u, v);
     return tex_mix(t, texels[t.i00], texels[t.i10], texels[t.i01], texels[t.i11]);
 }
+// k / 255 correctly rounded, for k = 0..255, without a division: one Newton correction of k * (1/255)
+// (checked against the division for all 256 values by the tests)
+PT_DEV float unorm8(uint32_t k)
+{
+    const float r = 0.003921568859368563f;
+    float kf = (float)k;
+    float q = kf * r;
+    float e = __builtin_fmaf(-q, 255.0f, kf);
+    return __builtin_fmaf(e, r, q);
+}
+PT_DEV float4 tex4_u8(const uint32_t* texels, int w, int h, float u, float v)
+{
+    Taps t = tex_taps(w, h, u, v);
+    uint32_t a = texels[t.i00], b = texels[t.i10], c = texels[t.i01], d = texels[t.i11];
+    return make_float4(tex_mix(t, unorm8(a & 255u), unorm8(b & 255u), unorm8(c & 255u), unorm8(d & 255u)),
+                       tex_mix(t, unorm8((a >> 8) & 255u), unorm8((b >> 8) & 255u), unorm8((c >> 8) & 255u), unorm8((d >> 8) & 255u)),
+                       tex_mix(t, unorm8((a >> 16) & 255u), unorm8((b >> 16) & 255u), unorm8((c >> 16) & 255u), unorm8((d >> 16) & 255u)),
+                       tex_mix(t, unorm8(a >> 24), unorm8(b >> 24), unorm8(c >> 24), unorm8(d >> 24)));
+}
+PT_DEV float tex1_u8(const uint8_t* texels, int w, int h, float u, float v)
+{
+    Taps t = tex_taps(w, h, u, v);
+    return tex_mix(t, unorm8(texels[t.i00]), unorm8(texels[t.i10]), unorm8(texels[t.i01]), unorm8(texels[t.i11]));
+}
+PT_DEV float4 tex4_any(const DTex& tx, float u, float v)
+{
+    return tx.format ? tex4_u8(reinterpret_cast<const uint32_t*>(tx.texels), tx.w, tx.h, u, v) : tex4(reinterpret_cast<const float*>(tx.texels), tx.w, tx.h, u, v);
+}
+PT_DEV float tex1_any(const DTex& tx, float u, float v)
+{
+    return tx.format ? tex1_u8(reinterpret_cast<const uint8_t*>(tx.texels), tx.w, tx.h, u, v) : tex1(reinterpret_cast<const float*>(tx.texels), tx.w, tx.h, u, v);
+}
 
 // ---------------------------------------------------------------- intersection
 // intersectors.cuh:59-71 (boxIntersectF)
@@ -327,19 +359,19 @@ PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& 
     float py = tA.y * w + tB.y * u + tC.y * v;
     if (tx_d) {
         const DTex tx = S.tex[tx_d - 1];
-        float4 r = tex4(tx.texels, tx.w, tx.h, px, py);
+        float4 r = tex4_any(tx, px, py);
         s.m.base = f3(r.x, r.y, r.z) * r.w;
         s.m.alpha = r.w;
         if (COUNT) taps++;
     }
-    if (tx_r) { const DTex tx = S.tex[tx_r - 1]; s.m.rough = tex1(tx.texels, tx.w, tx.h, px, py); if (COUNT) taps_r++; }
-    if (tx_m) { const DTex tx = S.tex[tx_m - 1]; s.m.metal = tex1(tx.texels, tx.w, tx.h, px, py); if (COUNT) taps_r++; }
-    if (tx_e) { const DTex tx = S.tex[tx_e - 1]; float r = tex1(tx.texels, tx.w, tx.h, px, py); s.m.emis = f3(r, r, r); if (COUNT) taps_r++; }
+    if (tx_r) { const DTex tx = S.tex[tx_r - 1]; s.m.rough = tex1_any(tx, px, py); if (COUNT) taps_r++; }
+    if (tx_m) { const DTex tx = S.tex[tx_m - 1]; s.m.metal = tex1_any(tx, px, py); if (COUNT) taps_r++; }
+    if (tx_e) { const DTex tx = S.tex[tx_e - 1]; float r = tex1_any(tx, px, py); s.m.emis = f3(r, r, r); if (COUNT) taps_r++; }
     if (tx_n) {
         F3 Tn, Bn;
         onb(s.n, Tn, Bn);
         const DTex tx = S.tex[tx_n - 1];
-        float4 r = tex4(tx.texels, tx.w, tx.h, px, py);
+        float4 r = tex4_any(tx, px, py);
         s.n = to_world(Tn, Bn, s.n, f3(r.x * 2.f - 1.f, r.y * 2.f - 1.f, r.z * 2.f - 1.f));
         if (COUNT) taps++;
     }

@@ -187,6 +187,8 @@ __global__ void detmath_probe_kernel(const float* __restrict__ x, const float* _
     o[5] = pt_powf(a, b); o[6] = pt_acosf(a); o[7] = pt_atan2f(a, b);
     o[8] = 1.0f / a; o[9] = __builtin_sqrtf(a); o[10] = a / b; o[11] = (float)pt_dm_pow((double)a, (double)b);
 }
+__global__ void unorm8_probe_kernel(float* __restrict__ out) { out[threadIdx.x] = unorm8(threadIdx.x); }
+void launch_unorm8_probe(float* out_dev, hipStream_t stream) { hipLaunchKernelGGL(unorm8_probe_kernel, dim3(1), dim3(256), 0, stream, out_dev); }
 void launch_detmath_probe(const float* x_dev, const float* y_dev, int n, float* out_dev, hipStream_t stream)
 {
     hipLaunchKernelGGL(detmath_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x_dev, y_dev, n, out_dev);

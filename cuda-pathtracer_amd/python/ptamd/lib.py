@@ -22,7 +22,7 @@ EXPORTS = [
     'pt_set_sky_mode', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
     'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
     'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
-    'pt_detmath_probe', 'pt_read_obj', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
+    'pt_detmath_probe', 'pt_unorm8_probe', 'pt_set_texture_packing', 'pt_read_obj', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
     'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
     'pt_host_build_bvh', 'pt_load_hdr', 'pt_load_texture_png', 'pt_build_env_cdf', 'pt_free', 'pt_camera_basis',
 ]
@@ -323,6 +323,14 @@ class Renderer:
         a, b = C.c_uint64(), C.c_uint64()
         check(lib().pt_scene_bytes(self.h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def set_texture_packing(self, on):
+        check(lib().pt_set_texture_packing(self.h, C.c_int(1 if on else 0)))
+
+    def unorm8_probe(self):
+        out = np.zeros(256, dtype=np.float32)
+        check(lib().pt_unorm8_probe(self.h, _p(out)))
+        return out
 
     def detmath_probe(self, x, y):
         x = np.ascontiguousarray(x, dtype=np.float32)

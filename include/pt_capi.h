@@ -165,6 +165,7 @@ int pt_render_frame(pt_ctx* ctx, pt_params* params);                    /* rende
 
 /* ---- textures and sky: image_loader.h:5-89, envmap.cpp:37-94 ---- */
 int pt_upload_texture(pt_ctx* ctx, const float* texels, int w, int h, int comps, uint64_t* handle_out); /* comps 4 = genTexture, 1 = genTexture_float; rows already V-flipped */
+int pt_set_texture_packing(pt_ctx* ctx, int on);                        /* on (default): textures whose values are all exactly k/255 are stored as bytes; the sampled values are the same */
 int pt_upload_envmap(pt_ctx* ctx, const float* rgba, const float* cdf, int w, int h, float sum, pt_params* params_io); /* generateCUDAenvmap + transfertToParams */
 int pt_set_sky_mode(pt_ctx* ctx, int mode);
 
@@ -201,6 +202,7 @@ int pt_enable_counters(pt_ctx* ctx, int on);                            /* instr
 int pt_stage_timing(pt_ctx* ctx, int on, double* extend_ms_out, uint64_t* extend_launches_out); /* HIP-event time of the extend kernel: returns the totals since the last call, then switches timing on/off and clears them */
 int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* tri_bytes); /* size of the flattened BVH in HBM */
 int pt_detmath_probe(pt_ctx* ctx, const float* x, const float* y, int n, float* out12); /* device evaluation of include/pt_detmath.h, 12 results per input pair */
+int pt_unorm8_probe(pt_ctx* ctx, float* out256);                         /* device evaluation of the byte -> float conversion of packed textures */
 
 /* ---- host-side producers (no GPU needed) ---- */
 typedef struct pt_host_scene pt_host_scene;

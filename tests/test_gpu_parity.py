@@ -35,6 +35,32 @@ def test_detmath_bits_match_host():
     r.close()
 
 
+def test_packed_texture_conversion_is_exact():
+    """Byte-packed textures rebuild k/255 without a division; all 256 values must equal the IEEE quotient, and a
+    render with packing off (fp32 texels) must give the same bits as with packing on."""
+    r = ptamd.Renderer()
+    got = r.unorm8_probe()
+    r.close()
+    want = np.arange(256, dtype=np.float32) / np.float32(255.0)
+    assert np.array_equal(bits(got), bits(want))
+    b = util.atrium(detail=0.3, env_size=(64, 32))
+    P = scenes.atrium_params(ptamd.default_params(64, 40))
+    out = []
+    for packing in (True, False):
+        r = ptamd.Renderer()
+        r.init(P)
+        r.set_texture_packing(packing)
+        for t in b.textures:
+            r.upload_texture(t)
+        r.upload_scene(b.tris, b.mats, b.idx, b.nodes)
+        r.upload_envmap(b.env, b.cdf, b.env_sum, P)
+        r.set_max_bounces(8)
+        r.render(P, 0, 2)
+        out.append(r.read_accum())
+        r.close()
+    assert np.array_equal(bits(out[0]), bits(out[1])) and out[0].sum() > 0
+
+
 @pytest.mark.parametrize('n_tri', [1, 5, 300, 20000])
 def test_closest_hit_bit_exact_vs_brute_force(n_tri):
     extent = {1: 50.0, 5: 50.0, 300: 60.0, 20000: 250.0}[n_tri]
@@ -385,3 +411,28 @@ def test_headless_front_end_end_to_end(tmp_path):
     assert r.returncode == 0, r.stderr
     assert np.array_equal(bits(lib.load_pfm(pfm)), bits(want))
     assert np.array_equal(np.asarray(Image.open(png)), orc.resolve_display(want, 4))
+
+
+@pytest.mark.parametrize('mode', MODES)
+def test_degenerate_sizes_and_scenes(mode):
+    """One-pixel and odd images, a scene of a single triangle (the tree is one leaf), an empty frame range, an
+    empty ray batch."""
+    one = util.soup(1, seed=11, extent=50.0, edge=30.0)
+    P = ptamd.default_params(1, 1)
+    P.isRendering = 1
+    P.rayOrigin = ptamd.Float3(float(one.tris['a'][0][0]), float(one.tris['a'][0][1]), float(one.tris['a'][0][2]) + 200.0)
+    for W, H in ((1, 1), (3, 5), (9, 2)):
+        P.windowSize = ptamd.Int2(W, H)
+        acc, ctr, img, want, st = _render_both(one, P, 0, 3, 8, mode)
+        _assert_radiance(acc, want)
+        assert ctr['rays'] == st['rays'] and ctr['samples'] == W * H * 3
+    r = one.renderer(P)
+    r.set_mode(mode)
+    r.render(P, 0, 2)
+    before = r.read_accum()
+    r.render(P, 2, 2)                       # empty range: nothing changes
+    assert np.array_equal(bits(r.read_accum()), bits(before))
+    assert len(r.trace_closest(np.zeros(0, dtype=ptamd.RAY_DTYPE))) == 0
+    with pytest.raises(ptamd.PtError):
+        r.render(P, 3, 2)
+    r.close()

@@ -41,9 +41,10 @@ class Bundle:
             S.sun = (params.sunDirection.x, params.sunDirection.y, params.sunDirection.z)
         return S
 
-    def renderer(self, params, device=0):
+    def renderer(self, params, device=0, pack_textures=True):
         r = ptamd.Renderer(device)
         r.init(params)
+        r.set_texture_packing(pack_textures)
         handles = [r.upload_texture(t) for t in self.textures]
         assert handles == list(range(1, len(handles) + 1))
         r.upload_scene(self.tris, self.mats, self.idx, self.nodes)
