@@ -506,7 +506,8 @@ PT_DEV F3 eval_clearcoat(const Mat& m, F3 V, F3 L, F3 H, float& pdf)            
     return f3(F, F, F) * D * G;
 }
 // :234-347 (DisneyEval_2)
-__device__ __noinline__ F3 eval(const Mat& m, bool is_inside, F3 V, F3 N, F3 L, float& pdf)
+// inlined on purpose: as a call, the material record travels through scratch memory
+__device__ inline F3 eval(const Mat& m, bool is_inside, F3 V, F3 N, F3 L, float& pdf)
 {
     pdf = 0.0;
     float eta = is_inside ? m.ior : 1.f / m.ior;
