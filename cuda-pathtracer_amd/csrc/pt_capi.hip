@@ -695,7 +695,7 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
             // all sample ids handed out and few paths left: finish them in one kernel instead of one stage
             // launch sequence per remaining path vertex
             if (c->drain_rays > 0 && c->wf_host_counters[WF_CTR_NEXT_SAMPLE] >= w.n_samples && c->wf_host_counters[WF_CTR_RAYS] <= (uint32_t)c->drain_rays) {
-                launch_wf_drain(w, c->scene, cam, ctr, c->stream);
+                launch_wf_drain(w, c->scene, cam, (int)c->wf_host_counters[WF_CTR_RAYS], ctr, c->stream);
                 HIP_TRY(hipGetLastError());
                 break;
             }

@@ -28,6 +28,7 @@ namespace ptamd {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kPlanThreads = 1024;      // the single-workgroup planning kernels
 
 // flags word: state[1:0] ch[3:2] inside[4] surface_scatter[5] sh_inside[6] nee_surface[7] nee_skip[8] v_inside[9] seg[15:10]
 PT_DEV uint32_t pack_flags(const Path& P)
@@ -707,23 +708,75 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_BSDF_
 }
 
 // ---------------------------------------------------------------- drain
-// End of a render: every sample id has been handed out and few slots still carry a path. Another
-// hundred stage launches for the longest paths would cost their launch latencies in sequence; instead
-// each remaining slot runs its sample to the end in one kernel (the same state machine, one slot per
-// lane, reference-order traversal with the LDS stack). Workgroup b handles the b-th block of the list
-// of slot blocks that hold rays.
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+// End of a render: every sample id has been handed out by the global counter and few slots still carry a
+// path. Another hundred stage launches for the longest paths would cost their launch latencies in
+// sequence; instead the remaining paths are gathered into a dense list and each runs its sample to the
+// end in one kernel (the same state machine, one path per lane, reference-order traversal with the LDS
+// stack). Sample ids a workgroup still holds in its chunk are started by the lanes whose slots belong
+// to that workgroup as they become free.
+
+// one workgroup: exclusive prefix of the ray counts of the listed slot blocks
+__global__ __launch_bounds__(kPlanThreads) void wf_drain_plan_kernel(uint32_t* __restrict__ counters, const uint32_t* __restrict__ chunk_rays,
+                                                                     const uint32_t* __restrict__ chunk_list, uint32_t* __restrict__ chunk_base)
+{
+    __shared__ uint32_t s_wave[kPlanThreads / 64];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int n = (int)counters[WF_CTR_RAY_CHUNKS];
+    uint32_t base = 0;
+    for (int tile = 0; tile < n; tile += kPlanThreads) {
+        int i = tile + tid;
+        uint32_t mine = i < n ? chunk_rays[chunk_list[i]] : 0u;
+        uint32_t incl = mine;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            uint32_t t = (uint32_t)__shfl_up((int)incl, dlt, 64);
+            if (lane >= dlt) incl += t;
+        }
+        if (lane == 63) s_wave[wid] = incl;
+        __syncthreads();
+        uint32_t woff = 0, total = 0;
+#pragma unroll
+        for (int j = 0; j < kPlanThreads / 64; j++) { uint32_t c = s_wave[j]; if (j < wid) woff += c; total += c; }
+        if (i < n) chunk_base[i] = base + woff + incl - mine;
+        base += total;
+        __syncthreads();
+    }
+    if (tid == 0) counters[WF_CTR_RAYS] = base;
+}
+
+// workgroup i: the slots of listed block i that carry a path, written densely at that block's base
+__global__ __launch_bounds__(kBlock) void wf_drain_gather_kernel(WfParams w, const uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ drain_list)
 {
     if (blockIdx.x >= w.counters[WF_CTR_RAY_CHUNKS]) return;
+    __shared__ uint32_t s_c[kBlock / 64];
     uint32_t slot = w.chunk_list[blockIdx.x] * (uint32_t)kBlock + threadIdx.x;
-    float4 rd4 = w.ray_d[slot];
-    const bool live = __float_as_int(rd4.w) != 0;      // lanes without a path stay for the wave-wide tally
+    bool live = __float_as_int(w.ray_d[slot].w) != 0;
+    unsigned long long m = __ballot(live);
+    const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    if (lane == 0) s_c[wid] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int j = 0; j < kBlock / 64; j++) if (j < wid) woff += s_c[j];
+    if (live) drain_list[chunk_base[blockIdx.x] + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, DCamera cam, const uint32_t* __restrict__ drain_list, DCounters* ctr)
+{
+    const uint32_t n_paths = w.counters[WF_CTR_RAYS];
+    if (blockIdx.x * (uint32_t)kBlock >= n_paths) return;
+    const uint32_t q = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
+    bool have = q < n_paths;             // lanes past the end stay for the wave-wide tally
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t nsamples = 0;
     Path P;
     SampleId id;
     P.state = ST_DONE;
-    if (live) {
+    uint32_t slot = 0;
+    if (have) {
+        slot = drain_list[q];
+        float4 rd4 = w.ray_d[slot];
         load_core(w, slot, P, id);
         load_light(w, slot, P);
         float4 ro4 = w.ray_o[slot];
@@ -732,43 +785,40 @@ __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, 
             P.so = f3(ro4.x, ro4.y, ro4.z); P.sd = f3(rd4.x, rd4.y, rd4.z);
         }
     }
-    // sample ids this workgroup still holds in its chunk (the global counter is exhausted, so nothing
-    // else will start them): lanes take them one by one as they become free
-    __shared__ uint32_t s_cur, s_end;
     uint32_t* cw = w.block_chunk + 2 * (size_t)(slot / kBlock);
-    if (threadIdx.x == 0) { s_cur = cw[0]; s_end = cw[1] < w.n_samples ? cw[1] : w.n_samples; }
-    __syncthreads();
-    uint32_t nsamples = 0;
-    bool have = live;
-    for (;;) {
-        if (have) {
-            while (P.state != ST_DONE) {
-                if (P.state == ST_AFTER) { after_light<COUNT>(S, cam, P, tl); continue; }
-                bool shadow = P.state == ST_SHADOW;
-                F3 ro = shadow ? P.so : P.o;
-                F3 rd = shadow ? P.sd : P.d;
-                Hit h = closest_hit<kBlock, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
-                if (COUNT) tl.rays++;
-                Surf info;
-                resolve_hit<COUNT>(S, h, rd, info, tl.taps, tl.taps_r);
-                if (shadow) on_shadow_hit<COUNT>(S, cam, P, info, tl);
-                else on_path_hit<COUNT>(S, cam, P, info, tl);
-            }
-            float v = P.result * 3.f;
-            w.staging[id.stage_index] = v > 0.f ? v : 0.f;
+    const uint32_t id_end = have ? (cw[1] < w.n_samples ? cw[1] : w.n_samples) : 0u;
+    while (have) {
+        while (P.state != ST_DONE) {
+            if (P.state == ST_AFTER) { after_light<COUNT>(S, cam, P, tl); continue; }
+            bool shadow = P.state == ST_SHADOW;
+            F3 ro = shadow ? P.so : P.o;
+            F3 rd = shadow ? P.sd : P.d;
+            Hit h = closest_hit<kBlock, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
+            if (COUNT) tl.rays++;
+            Surf info;
+            resolve_hit<COUNT>(S, h, rd, info, tl.taps, tl.taps_r);
+            if (shadow) on_shadow_hit<COUNT>(S, cam, P, info, tl);
+            else on_path_hit<COUNT>(S, cam, P, info, tl);
         }
-        uint32_t next = atomicAdd(&s_cur, 1u);
-        if (next >= s_end) break;
-        id = decode_sample(w, next);
-        begin_sample(P, cam, id.x, id.y, id.frame);
-        if (COUNT) nsamples++;
-        have = true;
+        float v = P.result * 3.f;
+        w.staging[id.stage_index] = v > 0.f ? v : 0.f;
+        // a sample id the slot's workgroup still holds?
+        have = false;
+        if (cw[0] < id_end) {
+            uint32_t next = atomicAdd(cw, 1u);
+            if (next < id_end) {
+                id = decode_sample(w, next);
+                begin_sample(P, cam, id.x, id.y, id.frame);
+                if (COUNT) nsamples++;
+                have = true;
+            }
+        }
     }
-    w.ray_d[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
-    P.state = ST_DONE;
-    store_core(w, slot, P, 0xFFFFFFFFu);
-    __syncthreads();
-    if (threadIdx.x == 0) { cw[0] = w.n_samples; cw[1] = w.n_samples; w.chunk_rays[slot / kBlock] = 0; }
+    if (q < n_paths) {
+        w.ray_d[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+        P.state = ST_DONE;
+        store_core(w, slot, P, 0xFFFFFFFFu);
+    }
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
 
@@ -796,7 +846,6 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate_kernel(WfParams w, DCame
 // ---------------------------------------------------------------- closest-hit batch through the production traversal
 // Runs before every extend launch (one workgroup): compacts the indices of the slot blocks that hold rays
 // into chunk_list, publishes their number, and resets the per-iteration counters.
-constexpr int kPlanThreads = 1024;
 __global__ __launch_bounds__(kPlanThreads) void wf_plan_extend_kernel(uint32_t* __restrict__ counters, const uint32_t* __restrict__ chunk_rays,
                                                                       uint32_t* __restrict__ chunk_list, int n_chunks)
 {
@@ -900,12 +949,20 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
     }
 }
 
-void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s)
+void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int max_paths, DCounters* ctr, hipStream_t s)
 {
-    dim3 grid((w.n_slots + kBlock - 1) / kBlock), block(kBlock);
-    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, w.n_slots / kBlock);
-    if (ctr) hipLaunchKernelGGL(wf_drain_kernel<true>, grid, block, 0, s, w, S, cam, ctr);
-    else hipLaunchKernelGGL(wf_drain_kernel<false>, grid, block, 0, s, w, S, cam, ctr);
+    const int n_blocks = w.n_slots / kBlock;
+    // the stage queues are idle now: their arrays hold the per-block bases and the dense list of slots
+    uint32_t* chunk_base = w.bsdf_count;
+    uint32_t* drain_list = w.bsdf_queue;
+    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, n_blocks);
+    hipLaunchKernelGGL(wf_drain_plan_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, chunk_base);
+    hipLaunchKernelGGL(wf_drain_gather_kernel, dim3(n_blocks), dim3(kBlock), 0, s, w, chunk_base, drain_list);
+    int max_blocks = (max_paths + kBlock - 1) / kBlock;
+    if (max_blocks > n_blocks) max_blocks = n_blocks;
+    if (max_blocks < 1) max_blocks = 1;
+    if (ctr) hipLaunchKernelGGL(wf_drain_kernel<true>, dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
+    else hipLaunchKernelGGL(wf_drain_kernel<false>, dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
 }
 
 void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, hipStream_t s)
