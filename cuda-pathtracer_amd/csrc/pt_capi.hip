@@ -64,7 +64,7 @@ struct pt_ctx {
     size_t n_nodes = 0;
     // wavefront pool
     int mode = PT_MODE_WAVEFRONT;
-    int pool_slots = 1 << 23;
+    int pool_slots = 1 << 24;
     int chunk_frames = 64;
     int refill_lanes = 8, leaf_vote = 12, extend_blocks_per_cu = 5, n_cus = 256;
     void* wf_block = nullptr;       // one allocation holding every slot array
