@@ -310,40 +310,19 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
 // ---------------------------------------------------------------- extend
 // Persistent waves over the pool's rays. Traversal lengths vary by more than 10x between rays, so a
 // wave that kept its 64 rays until the last one finished would run mostly empty (measured: about 6
-// of 64 lanes busy). Here a lane whose ray is finished takes the next untraced ray from a global
-// counter (one atomic per wave per refill) as soon as kRefillLanes lanes are idle, and leaf work is
-// postponed until kLeafVote lanes wait at a leaf (or nobody can descend), so each pass of the loop
-// does one kind of work for most lanes. The per-ray visiting order, and therefore the result and the
-// test counts, are exactly those of closest_hit().
-#ifndef PT_REFILL
-#define PT_REFILL 24
-#endif
-#ifndef PT_LEAFVOTE
-#define PT_LEAFVOTE 24
-#endif
-#ifndef PT_EXT_LDS
-#define PT_EXT_LDS 16
-#endif
-#ifndef PT_EXT_BLOCKS_PER_CU
-#define PT_EXT_BLOCKS_PER_CU 5
-#endif
-#ifndef PT_SPLIT_NODE_LOAD
-#define PT_SPLIT_NODE_LOAD 0
-#endif
-#ifndef PT_QUANT_NODES
-#define PT_QUANT_NODES 1   // production traversal reads the 32-byte compact nodes
-#endif
-#ifndef PT_BOX_FMA
-#define PT_BOX_FMA 1
-#endif
+// of 64 lanes busy). Here a lane whose ray is finished takes the next untraced ray (from a block of
+// 256 slots the wave took with one atomic) as soon as w.refill_lanes lanes are idle, and leaf work is
+// postponed until w.leaf_vote lanes wait at a leaf (or nobody can descend), so each pass of the loop
+// does one kind of work for most lanes.
+//   COUNT: walks the 64-byte fp32 binary nodes in the reference's order and tallies box and triangle
+//          tests, which then equal the oracle's counts.
+//   WIDE:  walks the 4-wide quantized nodes (closest hits do not depend on the visiting order).
+//   neither: the binary quantized nodes, for trees too deep for the 4-wide stack.
 #ifndef PT_STAMPS
-#define PT_STAMPS 0      // diagnostic build: per-section cycle stamps in the extend kernel
+#define PT_STAMPS 0      // diagnostic build: pass statistics of the extend kernel
 #endif
 constexpr int kRayChunk = 256;
-constexpr int kRefillLanes = PT_REFILL;
-constexpr int kLeafVote = PT_LEAFVOTE;
-constexpr int kExtendLds = PT_EXT_LDS;
-constexpr int kExtendBlocks = 256 * PT_EXT_BLOCKS_PER_CU;      // 256 CUs x the workgroups that fit one CU's LDS
+constexpr int kExtendLds = 16;          // stack entries per lane in LDS: 16 x 256 lanes x 8 B = 32 KB per workgroup, 5 workgroups per CU
 
 template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S, DCounters* ctr)
@@ -358,7 +337,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     // ray in grid coordinates for the compact nodes (uncounted build only)
     F3 oq = o, invq = o, noq = o;
     static_assert(!(COUNT && WIDE), "the counting build walks the binary tree the reference walks");
-    constexpr bool QUANT = !COUNT && (PT_QUANT_NODES || WIDE);
+    constexpr bool QUANT = !COUNT;
     Hit best; best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
     bool has_ray = false;
     bool more = true;
@@ -470,17 +449,11 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const uint32_t a = wd[3 * k], b = wd[3 * k + 1], c = wd[3 * k + 2];
-#if PT_BOX_FMA
                 // plane distances as q * inv - o * inv in one fused operation each; an axis the ray is parallel to
                 // gives inf - inf = NaN on both planes, which min/max ignore: the box only gets more conservative
                 float t0x = __builtin_fmaf((float)(a & 0xffffu), invq.x, noq.x), t1x = __builtin_fmaf((float)(b >> 16), invq.x, noq.x);
                 float t0y = __builtin_fmaf((float)(a >> 16), invq.y, noq.y),    t1y = __builtin_fmaf((float)(c & 0xffffu), invq.y, noq.y);
                 float t0z = __builtin_fmaf((float)(b & 0xffffu), invq.z, noq.z), t1z = __builtin_fmaf((float)(c >> 16), invq.z, noq.z);
-#else
-                float t0x = ((float)(a & 0xffffu) - oq.x) * invq.x, t1x = ((float)(b >> 16) - oq.x) * invq.x;
-                float t0y = ((float)(a >> 16) - oq.y) * invq.y,    t1y = ((float)(c & 0xffffu) - oq.y) * invq.y;
-                float t0z = ((float)(b & 0xffffu) - oq.z) * invq.z, t1z = ((float)(c >> 16) - oq.z) * invq.z;
-#endif
                 float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
                 float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
                 dk[k] = (tf > tn && tf > 0.f && tn < best.t) ? tn : 1e30f;
@@ -565,20 +538,21 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
             if (COUNT) tl.rays++;
             cur = PT_TRAV_EMPTY;
             if (finite3(o) && finite3(d)) {
-                inv = 1.0f / d;
+                // the quantized boxes carry two cells of padding (the root box 0.1 units): the hardware reciprocal's
+                // last-bit error cannot lose a box, and saves three IEEE divisions per ray
+                if (QUANT) inv = f3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                else inv = 1.0f / d;
                 if (COUNT) tl.box += 1;
                 float troot = box_entry(o, inv, S.root_min, S.root_max);
                 if (troot < best.t) cur = WIDE ? S.root_ref4 : S.root_ref;
                 if (QUANT) {
                     oq = (o - ld3(S.q_origin)) * ld3(S.q_inv_cell);
                     invq = inv * ld3(S.q_cell);
-#if PT_BOX_FMA
                     // an axis the ray is parallel to: a huge finite slope keeps q * inv - o * inv free of inf - inf and
                     // still puts both planes of a slab the origin is outside of on the same side (boxes carry two
                     // cells of padding, far more than the rounding of the products)
                     invq = f3(__builtin_fminf(__builtin_fmaxf(invq.x, -1e30f), 1e30f), __builtin_fminf(__builtin_fmaxf(invq.y, -1e30f), 1e30f),
                               __builtin_fminf(__builtin_fmaxf(invq.z, -1e30f), 1e30f));
-#endif
                     noq = f3(-(oq.x * invq.x), -(oq.y * invq.y), -(oq.z * invq.z));
                 }
             }
