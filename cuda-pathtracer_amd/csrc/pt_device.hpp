@@ -95,8 +95,10 @@ PT_DEV void philox_block(uint32_t key0, uint32_t c0, uint32_t& r0, uint32_t& r1,
     uint32_t x0 = c0, x1 = 0, x2 = 0, x3 = 0, k0 = key0, k1 = 0;
 #pragma unroll
     for (int r = 0; r < 10; r++) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, x0), lo0 = 0xD2511F53u * x0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, x2), lo1 = 0xCD9E8D57u * x2;
+        // one 32x32->64 multiply per product (v_mad_u64_u32) instead of separate high and low halves
+        unsigned long long p0 = (unsigned long long)0xD2511F53u * x0, p1 = (unsigned long long)0xCD9E8D57u * x2;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t n0 = hi1 ^ x1 ^ k0, n2 = hi0 ^ x3 ^ k1;
         x0 = n0; x1 = lo1; x2 = n2; x3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
