@@ -95,7 +95,15 @@ struct DCounters {
 
 // ---------------------------------------------------------------- wavefront pool
 // Path slots as a structure of 16-byte arrays (slot-indexed) plus the per-sample staging values.
-enum : int { WF_CTR_NEXT_SAMPLE = 0, WF_CTR_BSDF_COUNT = 1, WF_CTR_LIVE = 2, WF_CTR_LIVE_PREV = 3, WF_CTR_RAY_NEXT = 4, WF_CTR_RAY_CHUNKS = 5, WF_CTR_RAYS = 6, WF_CTR_WORDS = 8 };
+// device counters of the wavefront loop (one 32-bit word each)
+enum : int {
+    WF_CTR_NEXT_SAMPLE = 0,   // next sample id the global hand-out gives to a workgroup (in chunks)
+    WF_CTR_LIVE = 2,          // set by the shade stage when any slot still carries a path
+    WF_CTR_RAY_NEXT = 4,      // next entry of chunk_list the extend kernel hands to a wave
+    WF_CTR_RAY_CHUNKS = 5,    // entries in chunk_list
+    WF_CTR_RAYS = 6,          // rays waiting at the last planning pass
+    WF_CTR_WORDS = 8
+};
 struct WfParams {
     float4 *ray_o, *ray_d;          // pending ray; ray_d.w != 0 when the slot has a ray to trace
     float4 *hit;                    // (t, triangle, u, v)

@@ -127,22 +127,6 @@ PT_DEV void load_vertex(const WfParams& w, uint32_t slot, Path& P)
     m.sigA = f3(0.f, 0.f, 0.f); m.sigS = f3(0.f, 0.f, 0.f);     // not used after the vertex
 }
 
-// Hands `need` lanes consecutive values from a global counter with one atomic per wave.
-PT_DEV uint32_t wave_take(uint32_t* counter, bool need)
-{
-    unsigned long long mask = __ballot(need);
-    uint32_t id = 0;
-    if (mask != 0ull) {
-        int lane = (int)(threadIdx.x & 63u);
-        int leader = __ffsll((long long)mask) - 1;
-        uint32_t base = 0;
-        if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-        base = (uint32_t)__shfl((int)base, leader, 64);
-        id = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    }
-    return id;
-}
-
 // Sample ids are handed out per workgroup from a chunk of kSampleChunk consecutive ids that the
 // workgroup owns (four 8x8 tiles of one frame when the image is tiled). The chunk cursor lives in
 // global memory between launches; a new chunk costs one atomic on the global counter, so a launch over
@@ -855,9 +839,7 @@ __global__ __launch_bounds__(kPlanThreads) void wf_plan_extend_kernel(uint32_t* 
         __syncthreads();
     }
     if (tid == 0) {
-        counters[WF_CTR_LIVE_PREV] = counters[WF_CTR_LIVE];
         counters[WF_CTR_LIVE] = 0;
-        counters[WF_CTR_BSDF_COUNT] = 0;
         counters[WF_CTR_RAY_NEXT] = 0;
         counters[WF_CTR_RAY_CHUNKS] = base;
         counters[WF_CTR_RAYS] = rays;
