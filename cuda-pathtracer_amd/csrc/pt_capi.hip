@@ -55,6 +55,8 @@ struct pt_ctx {
     float* d_env = nullptr;
     float* d_cdf = nullptr;
     float* d_env_tables = nullptr;   // row table [H] followed by column table [H*W]
+    uint32_t* d_env_guides = nullptr; // row guide, column guides, one word of verification result
+    bool env_guides_ok = false, use_env_guides = true;
     DScene scene{};
     bool have_tris = false, have_bvh = false, have_mats = false, have_env = false;
     int max_bounces = 512;
@@ -135,6 +137,7 @@ void pt_destroy(pt_ctx* c)
     if (c->d_env) (void)hipFree(c->d_env);
     if (c->d_cdf) (void)hipFree(c->d_cdf);
     if (c->d_env_tables) (void)hipFree(c->d_env_tables);
+    if (c->d_env_guides) (void)hipFree(c->d_env_guides);
     if (c->own_accum) (void)hipFree(c->own_accum);
     if (c->display) (void)hipFree(c->display);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
@@ -532,11 +535,41 @@ int pt_upload_envmap(pt_ctx* c, const float* rgba, const float* cdf, int w, int 
     c->scene.env_row_table = c->d_env_tables; c->scene.env_col_table = c->d_env_tables + h;
     c->scene.env_rgba = c->d_env; c->scene.env_cdf = c->d_cdf;
     c->scene.env_w = w; c->scene.env_h = h; c->scene.env_sum = sum;
+    // guide tables for the two CDF searches, trusted only if they reproduce the bisection at every breakpoint
+    c->scene.env_fast = 0;
+    c->env_guides_ok = false;
+    if (c->d_env_guides) { (void)hipFree(c->d_env_guides); c->d_env_guides = nullptr; }
+    if (sum > 0.f && sum < 1e30f && w <= 65535 && h <= 65535) {
+        size_t words = (size_t)kEnvRowBuckets + (size_t)h * kEnvColBuckets + 1;
+        HIP_TRY(hipMalloc((void**)&c->d_env_guides, words * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(c->d_env_guides, 0, words * sizeof(uint32_t), c->stream));
+        c->scene.env_row_guide = c->d_env_guides;
+        c->scene.env_col_guide = c->d_env_guides + kEnvRowBuckets;
+        c->scene.env_row_scale = (float)kEnvRowBuckets / sum;
+        c->scene.env_col_scale = (float)kEnvColBuckets / sum;
+        uint32_t* d_bad = c->d_env_guides + words - 1;
+        launch_env_guides(c->scene, c->d_env_guides, c->d_env_guides + kEnvRowBuckets, d_bad, c->stream);
+        HIP_TRY(hipGetLastError());
+        uint32_t bad = 1;
+        HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->env_guides_ok = bad == 0;
+        c->scene.env_fast = (c->env_guides_ok && c->use_env_guides) ? 1 : 0;
+    }
     c->have_env = true;
     if (params_io) {
         params_io->envMap_size.x = w; params_io->envMap_size.y = h; params_io->envmap_sum = sum;
         params_io->cubeMap = 1; params_io->envMap_cdf = 1;
     }
+    return PT_OK;
+}
+
+int pt_set_env_guides(pt_ctx* c, int on, int* verified_out)
+{
+    if (!c) { set_error("null context"); return PT_ERR_ARG; }
+    c->use_env_guides = on != 0;
+    c->scene.env_fast = (c->env_guides_ok && c->use_env_guides) ? 1 : 0;
+    if (verified_out) *verified_out = c->env_guides_ok ? 1 : 0;
     return PT_OK;
 }
 

@@ -664,26 +664,58 @@ PT_DEV float4 eval_envmap(const DScene& S, F3 dir)
     float pdf = disney::luminance(f3(r.x, r.y, r.z)) / S.env_sum;
     return make_float4(r.x, r.y, r.z, (pdf * S.env_w * S.env_h) / (PT_TWO_PI * PT_PI * pt_sinf(theta)));
 }
+// binarySearch of envmap_cuda.cu:28-57 on one table of n entries: the index the reference's bisection ends at.
+template <bool COUNT>
+PT_DEV int env_bisect(const float* __restrict__ table, int n, float xi, uint32_t& taps_r)
+{
+    int lower = 0, upper = n - 1;
+    while (lower < upper) {
+        int mid = (lower + upper) >> 1;
+        float c = table[mid];
+        if (COUNT) taps_r++;
+        if (xi < c) upper = mid; else lower = mid + 1;
+    }
+    return lower;
+}
+// The same index with fewer dependent loads. Entries 1.. of a table are non-decreasing (a running sum, filtered),
+// so the bisection ends at the first index >= 1 whose entry exceeds xi wherever it starts; the guide narrows the
+// start to the bucket of xi. Entry 0 is the odd one (the filter wraps it around to the end of the table) and the
+// bisection only consults it when xi is below entry 1. Whether this holds for a given map is not assumed: every
+// breakpoint is compared with env_bisect when the map is uploaded.
+PT_DEV int env_guided(const float* __restrict__ table, int n, float xi, uint32_t guide)
+{
+    int lower = (int)(guide & 0xffffu), upper = (int)(guide >> 16);
+    while (lower < upper) {
+        int mid = (lower + upper) >> 1;
+        if (xi < table[mid]) upper = mid; else lower = mid + 1;
+    }
+    if (lower == 1 && n > 1 && xi < table[0]) lower = 0;
+    return lower;
+}
+PT_DEV uint32_t env_bucket(float xi, float scale, int buckets)
+{
+    float f = xi * scale;
+    int k = f >= 0.f ? (int)f : 0;          // NaN and negatives go to bucket 0
+    return (uint32_t)(k < buckets ? k : buckets - 1);
+}
 template <bool COUNT>
 PT_DEV F2 env_search(const DScene& S, float xi, uint32_t& taps_r)
 {
-    int lower = 0, upper = S.env_h - 1;
-    while (lower < upper) {
-        int mid = (lower + upper) >> 1;
-        // the value tex1(cdf, 1, mid/H) the reference looks up here, tabulated when the map was uploaded
-        float c = S.env_row_table[mid];
-        if (COUNT) taps_r++;
-        if (xi < c) upper = mid; else lower = mid + 1;
+    int row, col;
+    if (!COUNT && S.env_fast) {
+        row = env_guided(S.env_row_table, S.env_h, xi, S.env_row_guide[env_bucket(xi, S.env_row_scale, kEnvRowBuckets)]);
+        int y = (int)clamp_((float)row, 0.f, (float)(S.env_h - 1));
+        col = env_guided(S.env_col_table + (size_t)y * S.env_w, S.env_w, xi, S.env_col_guide[(size_t)y * kEnvColBuckets + env_bucket(xi, S.env_col_scale, kEnvColBuckets)]);
+        int x = (int)clamp_((float)col, 0.f, (float)(S.env_w - 1));
+        F2 uv = {(float)x / (float)S.env_w, (float)y / (float)S.env_h};
+        return uv;
     }
-    int y = (int)clamp_((float)lower, 0.f, (float)(S.env_h - 1));
-    lower = 0; upper = S.env_w - 1;
-    while (lower < upper) {
-        int mid = (lower + upper) >> 1;
-        float c = S.env_col_table[(size_t)y * S.env_w + mid];     // tex1(cdf, mid/W, y/H), tabulated
-        if (COUNT) taps_r++;
-        if (xi < c) upper = mid; else lower = mid + 1;
-    }
-    int x = (int)clamp_((float)lower, 0.f, (float)(S.env_w - 1));
+    // the value tex1(cdf, 1, mid/H) the reference looks up in the row search and tex1(cdf, mid/W, y/H) in the
+    // column search, tabulated when the map was uploaded
+    row = env_bisect<COUNT>(S.env_row_table, S.env_h, xi, taps_r);
+    int y = (int)clamp_((float)row, 0.f, (float)(S.env_h - 1));
+    col = env_bisect<COUNT>(S.env_col_table + (size_t)y * S.env_w, S.env_w, xi, taps_r);
+    int x = (int)clamp_((float)col, 0.f, (float)(S.env_w - 1));
     F2 uv = {(float)x / (float)S.env_w, (float)y / (float)S.env_h};
     return uv;
 }

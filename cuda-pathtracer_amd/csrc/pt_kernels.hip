@@ -175,6 +175,69 @@ void launch_env_tables(const float* cdf_dev, int w, int h, float* row_table_dev,
     hipLaunchKernelGGL(env_tables_kernel, dim3((w * h + 255) / 256), dim3(256), 0, stream, cdf_dev, w, h, row_table_dev, col_table_dev);
 }
 
+// ---------------------------------------------------------------- environment search guides
+// One workgroup per table (blockIdx 0: the row table, blockIdx 1 + y: row y of the column table).
+// Bucket k covers the xi with (int)(xi * scale) == k; its range runs from the index the search ends at for
+// the smallest such xi to the index for the largest, both taken a little wide.
+PT_DEV int env_first_above(const float* __restrict__ table, int n, float xi)       // first index in [1, n-1) with xi < entry, else n - 1
+{
+    int lower = 1 < n - 1 ? 1 : n - 1, upper = n - 1;
+    while (lower < upper) {
+        int mid = (lower + upper) >> 1;
+        if (xi < table[mid]) upper = mid; else lower = mid + 1;
+    }
+    return lower;
+}
+__global__ __launch_bounds__(256) void env_guides_kernel(const float* __restrict__ row_table, const float* __restrict__ col_table, int w, int h,
+                                                         float row_scale, float col_scale, uint32_t* __restrict__ row_guide, uint32_t* __restrict__ col_guide)
+{
+    const bool rows = blockIdx.x == 0;
+    const float* table = rows ? row_table : col_table + (size_t)(blockIdx.x - 1) * w;
+    const int n = rows ? h : w, buckets = rows ? kEnvRowBuckets : kEnvColBuckets;
+    const float scale = rows ? row_scale : col_scale;
+    uint32_t* guide = rows ? row_guide : col_guide + (size_t)(blockIdx.x - 1) * kEnvColBuckets;
+    for (int k = threadIdx.x; k < buckets; k += 256) {
+        float lo_xi = ((float)k - 0.01f) / scale, hi_xi = ((float)k + 1.01f) / scale;
+        int lo = env_first_above(table, n, lo_xi);
+        int hi = k == buckets - 1 ? n - 1 : env_first_above(table, n, hi_xi);
+        guide[k] = (uint32_t)lo | ((uint32_t)hi << 16);
+    }
+}
+// Compares the guided search with the reference's bisection at every value where either can change its answer:
+// each table entry and its two neighbours in float order, and the floats around every bucket edge.
+__global__ __launch_bounds__(256) void env_verify_kernel(DScene S, uint32_t* __restrict__ mismatches)
+{
+    const bool rows = blockIdx.x == 0;
+    const float* table = rows ? S.env_row_table : S.env_col_table + (size_t)(blockIdx.x - 1) * S.env_w;
+    const int n = rows ? S.env_h : S.env_w, buckets = rows ? kEnvRowBuckets : kEnvColBuckets;
+    const float scale = rows ? S.env_row_scale : S.env_col_scale;
+    const uint32_t* guide = rows ? S.env_row_guide : S.env_col_guide + (size_t)(blockIdx.x - 1) * kEnvColBuckets;
+    uint32_t bad = 0, dummy = 0;
+    auto check = [&](float xi) {
+        if (!(xi >= 0.f)) return;
+        int want = env_bisect<false>(table, n, xi, dummy);
+        int got = env_guided(table, n, xi, guide[env_bucket(xi, scale, buckets)]);
+        if (want != got) bad++;
+    };
+    auto around = [&](float v, int reach) {
+        uint32_t b = __float_as_uint(v);
+        for (int d = -reach; d <= reach; d++) {
+            long long nb = (long long)b + d;
+            if (nb >= 0 && nb < 0x7f800000ll) check(__uint_as_float((uint32_t)nb));
+        }
+    };
+    for (int i = threadIdx.x; i < n; i += 256) around(table[i], 1);
+    for (int k = threadIdx.x; k <= buckets; k += 256) around((float)k / scale, 8);
+    if (threadIdx.x == 0) { check(0.f); check(S.env_sum); check(S.env_sum * 2.f); }
+    if (bad) atomicAdd(mismatches, bad);
+}
+void launch_env_guides(const DScene& S, uint32_t* row_guide_dev, uint32_t* col_guide_dev, uint32_t* mismatches_dev, hipStream_t stream)
+{
+    hipLaunchKernelGGL(env_guides_kernel, dim3(1 + S.env_h), dim3(256), 0, stream, S.env_row_table, S.env_col_table, S.env_w, S.env_h,
+                       S.env_row_scale, S.env_col_scale, row_guide_dev, col_guide_dev);
+    hipLaunchKernelGGL(env_verify_kernel, dim3(1 + S.env_h), dim3(256), 0, stream, S, mismatches_dev);
+}
+
 // ---------------------------------------------------------------- numerics probe
 // Evaluates the pinned transcendentals on the device so tests can compare bits with the host.
 __global__ void detmath_probe_kernel(const float* __restrict__ x, const float* __restrict__ y, int n, float* __restrict__ out)

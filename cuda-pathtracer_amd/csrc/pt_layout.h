@@ -72,6 +72,13 @@ struct DScene {
     const float* env_cdf;
     const float* env_row_table;   // [H]   filtered CDF lookups of the row search (envmap_cuda.cu:33)
     const float* env_col_table;   // [H*W] filtered CDF lookups of the column search (envmap_cuda.cu:46)
+    // Guide tables of the two searches: for a bucket of xi (xi * scale, truncated) the range of table
+    // indices the search can end in, lo | hi << 16. Used only when a check of every breakpoint at upload
+    // found the guided search equal to the reference's bisection (env_fast).
+    const uint32_t* env_row_guide;   // [kEnvRowBuckets]
+    const uint32_t* env_col_guide;   // [H][kEnvColBuckets]
+    float env_row_scale, env_col_scale;
+    int env_fast;
     int env_w, env_h;
     float env_sum;
     int sky_mode;
@@ -80,6 +87,9 @@ struct DScene {
     int root_ref;
     int n_tris;
 };
+
+constexpr int kEnvRowBuckets = 512;
+constexpr int kEnvColBuckets = 128;
 
 struct DCamera {
     float origin[3], ww[3], uu[3], vv[3];
