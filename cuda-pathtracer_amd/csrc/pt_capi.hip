@@ -1065,6 +1065,16 @@ int pt_read_obj(const char* obj_path, const char* model_dir, const char* sub_dir
     *out = hs;
     return PT_OK;
 }
+int pt_read_obj_general(const char* obj_path, const char* model_dir, const char* sub_dir, float scale, pt_host_scene** out)
+{
+    if (!obj_path || !out || !(scale > 0.f)) { set_error("pt_read_obj_general: bad argument"); return PT_ERR_ARG; }
+    pt_host_scene* hs = new (std::nothrow) pt_host_scene();
+    if (!hs) { set_error("out of memory"); return PT_ERR_NOMEM; }
+    int rc = read_obj_general(obj_path, model_dir, sub_dir, scale, hs->s);
+    if (rc != PT_OK) { delete hs; *out = nullptr; return rc; }
+    *out = hs;
+    return PT_OK;
+}
 void pt_host_scene_free(pt_host_scene* s) { delete s; }
 int pt_host_scene_counts(const pt_host_scene* s, int* n_tri, int* n_mat, int* n_tex)
 {

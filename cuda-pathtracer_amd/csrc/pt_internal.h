@@ -22,6 +22,7 @@ struct HostScene {
 };
 
 int read_obj(const char* obj_path, const char* model_dir, const char* sub_dir, HostScene& out);
+int read_obj_general(const char* obj_path, const char* model_dir, const char* sub_dir, float scale, HostScene& out);
 int load_hdr(const char* path, float** rgba_out, int* w, int* h);
 void build_env_cdf(const float* rgba, int w, int h, float* cdf_out, float* sum_out);
 int save_png(const char* path, const uint8_t* rgba, int w, int h);

@@ -235,6 +235,105 @@ int read_obj(const char* obj_path, const char* model_dir, const char* sub_dir, H
     return PT_OK;
 }
 
+// ---------------------------------------------------------------- general OBJ reader
+// The reference reader above accepts only what the reference accepts (triangles, one face syntax per file,
+// the index reset of file_reader.h:386-397). This one reads what exporters actually write: polygons (fan
+// triangulation), "v", "v/vt", "v//vn" and "v/vt/vn" corners mixed freely, negative (relative) indices,
+// any whitespace, several material libraries; a corner without a normal gets the face normal. Same output
+// records, same material library reader.
+int read_obj_general(const char* obj_path, const char* model_dir, const char* sub_dir, float scale, HostScene& sc)
+{
+    std::ifstream f(obj_path);
+    if (!f.is_open()) { set_error("cannot open model %s", obj_path); return PT_ERR_IO; }
+    std::string mdir = model_dir ? model_dir : "";
+    if (!mdir.empty() && mdir.back() != '/') mdir.push_back('/');
+    std::string sdir = sub_dir ? sub_dir : "";
+    std::vector<pt_float3> pts, nrm;
+    std::vector<pt_float2> uvs;
+    int cur_mat = 0, lineno = 0;
+    std::string text;
+    auto trim = [](std::string v) { size_t a = v.find_first_not_of(" \t\r"); size_t b = v.find_last_not_of(" \t\r"); return a == std::string::npos ? std::string() : v.substr(a, b - a + 1); };
+    struct Corner { int p, t, n; };
+    std::vector<Corner> poly;
+    while (std::getline(f, text)) {
+        lineno++;
+        const char* c = text.c_str();
+        while (*c == ' ' || *c == '\t') c++;
+        if (*c == '#' || *c == 0 || *c == '\r') continue;
+        const char* k = c;
+        while (*c && *c != ' ' && *c != '\t' && *c != '\r') c++;
+        std::string key(k, c);
+        if (key == "v" || key == "vn" || key == "vt") {
+            float v[3] = {0.f, 0.f, 0.f};
+            int got = 0;
+            for (; got < 3; got++) { char* e = nullptr; v[got] = strtof(c, &e); if (e == c) break; c = e; }
+            if (got < (key == "vt" ? 2 : 3)) { set_error("%s:%d: malformed %s", obj_path, lineno, key.c_str()); return PT_ERR_IO; }
+            if (key == "v") pts.push_back(pt_float3{v[0] * scale, v[1] * scale, v[2] * scale});
+            else if (key == "vn") nrm.push_back(pt_float3{v[0], v[1], v[2]});
+            else uvs.push_back(pt_float2{v[0], v[1]});
+        } else if (key == "f") {
+            poly.clear();
+            for (;;) {
+                while (*c == ' ' || *c == '\t') c++;
+                if (*c == 0 || *c == '\r') break;
+                Corner q{0, 0, 0};
+                bool hp = false, ht = false, hn = false;
+                char* e = nullptr;
+                long v = strtol(c, &e, 10);
+                if (e == c) { set_error("%s:%d: malformed face", obj_path, lineno); return PT_ERR_IO; }
+                q.p = (int)v; hp = true; c = e;
+                if (*c == '/') {
+                    c++;
+                    if (*c != '/') { v = strtol(c, &e, 10); if (e != c) { q.t = (int)v; ht = true; c = e; } }
+                    if (*c == '/') { c++; v = strtol(c, &e, 10); if (e != c) { q.n = (int)v; hn = true; c = e; } }
+                }
+                auto fix = [&](int idx, size_t count, bool have, const char* what) -> int {
+                    if (!have) return -1;
+                    long r = idx > 0 ? idx - 1 : (long)count + idx;
+                    if (idx == 0 || r < 0 || r >= (long)count) { set_error("%s:%d: %s index %d out of range (%zu defined)", obj_path, lineno, what, idx, count); return -2; }
+                    return (int)r;
+                };
+                q.p = fix(q.p, pts.size(), hp, "vertex"); q.t = fix(q.t, uvs.size(), ht, "texcoord"); q.n = fix(q.n, nrm.size(), hn, "normal");
+                if (q.p == -2 || q.t == -2 || q.n == -2) return PT_ERR_IO;
+                poly.push_back(q);
+            }
+            if (poly.size() < 3) { set_error("%s:%d: face with fewer than three corners", obj_path, lineno); return PT_ERR_IO; }
+            for (size_t j = 1; j + 1 < poly.size(); j++) {
+                const Corner q[3] = {poly[0], poly[j], poly[j + 1]};
+                pt_triangle T;
+                memset(&T, 0, sizeof(T));
+                T.a = pts[q[0].p]; T.b = pts[q[1].p]; T.c = pts[q[2].p];
+                T.matIndex = cur_mat;
+                pt_float3 e1{T.b.x - T.a.x, T.b.y - T.a.y, T.b.z - T.a.z}, e2{T.c.x - T.a.x, T.c.y - T.a.y, T.c.z - T.a.z};
+                pt_float3 g{e1.y * e2.z - e2.y * e1.z, e1.z * e2.x - e2.z * e1.x, e1.x * e2.y - e2.x * e1.y};
+                float gl = g.x * g.x + g.y * g.y + g.z * g.z;
+                pt_float3 face = gl > 0.f ? unit3(g) : pt_float3{0.f, 1.f, 0.f};
+                pt_float3* ns[3] = {&T.nA, &T.nB, &T.nC};
+                pt_float2* ts[3] = {&T.tA, &T.tB, &T.tC};
+                for (int m = 0; m < 3; m++) {
+                    if (q[m].n >= 0) { pt_float3 v = nrm[q[m].n]; *ns[m] = (v.x * v.x + v.y * v.y + v.z * v.z) > 0.f ? unit3(v) : face; }
+                    else *ns[m] = face;
+                    if (q[m].t >= 0) *ts[m] = uvs[q[m].t];
+                }
+                sc.tris.push_back(T);
+            }
+        } else if (key == "usemtl") {
+            std::string name = trim(c);
+            cur_mat = 0;
+            for (size_t i = 0; i < sc.mat_names.size(); i++) if (sc.mat_names[i] == name) { cur_mat = (int)i; break; }
+        } else if (key == "mtllib") {
+            std::string lib = trim(c);
+            int rc = read_mtl(mdir + sdir + lib, mdir + sdir, sc);
+            if (rc != PT_OK) return rc;
+        }
+    }
+    if (sc.tris.empty()) { set_error("%s: no faces", obj_path); return PT_ERR_IO; }
+    if (sc.mats.empty()) { pt_material m; default_material(m); sc.mats.push_back(m); sc.mat_names.push_back(""); }
+    sc.tri_idx.resize(sc.tris.size());
+    for (size_t i = 0; i < sc.tris.size(); i++) sc.tri_idx[i] = (int)i;
+    return PT_OK;
+}
+
 // ---------------------------------------------------------------- Radiance RGBE, hdr_loader.h:47-281
 namespace {
 bool starts(const char* line, const char* id, const char** rest)

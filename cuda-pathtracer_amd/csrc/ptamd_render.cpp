@@ -36,6 +36,8 @@ void usage()
         "  --angle AX,AY     camera angles in radians (default 0,0)\n"
         "  --fov F           field-of-view factor (default 1)\n"
         "  --dof S --focal D thin lens strength and focal distance (default 0, 200)\n"
+        "  --general-obj     read polygons, mixed corner syntax, negative indices (default: the reference's reader)\n"
+        "  --scale S         model scale with --general-obj (default 100, the reference's)\n"
         "  --preview         normal-dot-view preview instead of path tracing\n"
         "  --sunsky          sun/sky gradient instead of the environment map\n"
         "  --frames-per-call N   1 = call pt_render_frame per sample like the application; 0 = one headless call (default)\n"
@@ -65,7 +67,8 @@ int main(int argc, char** argv)
     std::string obj, dir, subdir, hdr, out = "out.png", pfm, resume;
     int W = 1920, H = 1080, spp = 64, bounces = 512, gpu = 0, per_call = 0, resume_frames = 0;
     float origin[3] = {0.f, 1.5f, 5.f}, angle[2] = {0.f, 0.f}, fov = 1.f, dof = 0.f, focal = 200.f, post[3] = {1.f, 1.f, 1.f};
-    bool preview = false, sunsky = false, use_post = false;
+    bool preview = false, sunsky = false, use_post = false, general = false;
+    float scale = 100.f;
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
         auto val = [&]() -> const char* { if (i + 1 >= argc) usage(); return argv[++i]; };
@@ -88,6 +91,8 @@ int main(int argc, char** argv)
         else if (a == "--dof") dof = std::strtof(val(), nullptr);
         else if (a == "--focal") focal = std::strtof(val(), nullptr);
         else if (a == "--post") { if (!parse_floats(val(), post, 3)) usage(); use_post = true; }
+        else if (a == "--general-obj") general = true;
+        else if (a == "--scale") scale = std::strtof(val(), nullptr);
         else if (a == "--preview") preview = true;
         else if (a == "--sunsky") sunsky = true;
         else usage();
@@ -116,7 +121,8 @@ int main(int argc, char** argv)
 
     // ---- initScene
     pt_host_scene* hs = nullptr;
-    must(pt_read_obj(obj.c_str(), dir.c_str(), subdir.c_str(), &hs), "reading the model");
+    if (general) must(pt_read_obj_general(obj.c_str(), dir.c_str(), subdir.c_str(), scale, &hs), "reading the model");
+    else must(pt_read_obj(obj.c_str(), dir.c_str(), subdir.c_str(), &hs), "reading the model");
     int n_tri = 0, n_mat = 0, n_tex = 0;
     must(pt_host_scene_counts(hs, &n_tri, &n_mat, &n_tex), "model");
     std::printf("model: %d triangles, %d materials, %d texture files (%.2f s)\n", n_tri, n_mat, n_tex, seconds());

@@ -22,7 +22,7 @@ EXPORTS = [
     'pt_set_sky_mode', 'pt_set_env_guides', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
     'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
     'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
-    'pt_detmath_probe', 'pt_unorm8_probe', 'pt_set_texture_packing', 'pt_read_obj', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
+    'pt_detmath_probe', 'pt_unorm8_probe', 'pt_set_texture_packing', 'pt_read_obj', 'pt_read_obj_general', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
     'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
     'pt_host_build_bvh', 'pt_load_hdr', 'pt_load_texture_png', 'pt_build_env_cdf', 'pt_free', 'pt_camera_basis',
 ]
@@ -67,9 +67,12 @@ def _p(a):
 class HostScene:
     """Result of pt_read_obj: triangles, index array, materials and the texture files the MTL names."""
 
-    def __init__(self, obj_path, model_dir, sub_dir=''):
+    def __init__(self, obj_path, model_dir, sub_dir='', general=False, scale=100.0):
         h = C.c_void_p()
-        check(lib().pt_read_obj(obj_path.encode(), model_dir.encode(), sub_dir.encode(), C.byref(h)))
+        if general:
+            check(lib().pt_read_obj_general(obj_path.encode(), model_dir.encode(), sub_dir.encode(), C.c_float(scale), C.byref(h)))
+        else:
+            check(lib().pt_read_obj(obj_path.encode(), model_dir.encode(), sub_dir.encode(), C.byref(h)))
         try:
             nt, nm, nx = C.c_int(), C.c_int(), C.c_int()
             check(lib().pt_host_scene_counts(h, C.byref(nt), C.byref(nm), C.byref(nx)))

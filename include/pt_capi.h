@@ -209,6 +209,7 @@ int pt_unorm8_probe(pt_ctx* ctx, float* out256);                         /* devi
 typedef struct pt_host_scene pt_host_scene;
 /* readObjFile, file_reader.h:217; model_dir replaces the hard-wired "assets/models/" prefix (file_reader.h:51,147) */
 int pt_read_obj(const char* obj_path, const char* model_dir, const char* sub_dir, pt_host_scene** out);
+int pt_read_obj_general(const char* obj_path, const char* model_dir, const char* sub_dir, float scale, pt_host_scene** out); /* same output for files the reference reader (file_reader.h:217-425) cannot take: polygons, mixed corner syntax, negative indices, more vertices than faces, no normals (face normal); scale 100 is the reference's */
 void pt_host_scene_free(pt_host_scene* s);
 int pt_host_scene_counts(const pt_host_scene* s, int* n_tri, int* n_mat, int* n_tex);
 pt_triangle* pt_host_scene_triangles(pt_host_scene* s);

@@ -436,3 +436,40 @@ def test_degenerate_sizes_and_scenes(mode):
     with pytest.raises(ptamd.PtError):
         r.render(P, 3, 2)
     r.close()
+
+
+def test_guided_environment_search_is_the_bisection():
+    """sampleEnvMap's two bisections start from guide tables when the upload-time check of every breakpoint passed;
+    renders with the guides on and off must agree bit for bit, on maps of very different shape."""
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(64, 48))
+    rng = np.random.default_rng(3)
+    onehot = np.zeros((50, 100, 4), np.float32); onehot[7, 93, :3] = 1000.0; onehot[30, 2, :3] = 1e-3
+    maps = [b.env,
+            np.concatenate([rng.uniform(0, 2, (64, 128, 3)).astype(np.float32) ** 6, np.zeros((64, 128, 1), np.float32)], -1),
+            np.concatenate([np.full((17, 33, 3), 0.5, np.float32), np.zeros((17, 33, 1), np.float32)], -1),
+            onehot]
+    for env in maps:
+        cdf, total = lib.build_env_cdf(env)
+        out = []
+        for on in (True, False):
+            r = ptamd.Renderer(); r.init(P)
+            r.upload_scene(b.tris, b.mats, b.idx, b.nodes)
+            r.upload_envmap(env, cdf, total, P)
+            verified = r.set_env_guides(on)
+            r.set_max_bounces(6)
+            r.render(P, 0, 3)
+            out.append(r.read_accum())
+            r.close()
+        assert verified, 'the guide tables of this map did not pass the check'
+        assert np.array_equal(bits(out[0]), bits(out[1]))
+    S = b.oracle(P)
+    S.env_rgba = np.ascontiguousarray(maps[1]); S.env_cdf, S.env_sum = lib.build_env_cdf(maps[1])
+    want, _ = orc.render(S, P, 0, 3, 6)
+    r = ptamd.Renderer(); r.init(P)
+    r.upload_scene(b.tris, b.mats, b.idx, b.nodes)
+    r.upload_envmap(maps[1], S.env_cdf, S.env_sum, P)
+    r.set_max_bounces(6)
+    r.render(P, 0, 3)
+    _assert_radiance(r.read_accum(), want)
+    r.close()
