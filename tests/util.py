@@ -5,7 +5,6 @@ import numpy as np
 
 import ptamd
 from ptamd import lib, scenes
-import orc
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCRATCH = os.path.join(ROOT, 'tests', '_scratch')
@@ -32,6 +31,7 @@ class Bundle:
             self.cdf, self.env_sum = lib.build_env_cdf(env)
 
     def oracle(self, params=None):
+        import orc          # the CPU oracle is a checker: nothing on the render path imports it
         S = orc.Scene(self.tris, self.mats, self.idx, self.nodes, textures=self.textures, sky_mode=self.sky_mode)
         if self.env is not None:
             S.env_rgba = np.ascontiguousarray(self.env, np.float32)
