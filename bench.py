@@ -49,6 +49,8 @@ def main():
     ap.add_argument('--cpu-spp', type=int, default=12, help='frames the CPU oracle renders for the baseline (about 15 s on 16 cores)')
     ap.add_argument('--mode', choices=['wavefront', 'single_kernel'], default='wavefront')
     ap.add_argument('--pool', type=int, default=0, help='wavefront pool slots (0 = library default)')
+    ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl is RCCL; gloo lets several ranks rehearse on one GPU)')
+    ap.add_argument('--device', type=int, default=-1, help='GPU to use (default: LOCAL_RANK)')
     ap.add_argument('--fp32-textures', action='store_true', help='keep 8-bit textures as fp32 texels instead of bytes')
     ap.add_argument('--drain', type=int, default=-1, help='finish the last paths in one kernel once at most this many remain (-1 = library default, 0 = never)')
     ap.add_argument('--node-width', type=int, default=4, help='4-wide or binary (2) compact nodes in the traversal kernel')
@@ -69,9 +71,13 @@ def main():
             raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the render path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
+    device = local_rank if args.device < 0 else args.device
+    torch.cuda.set_device(device)
     if world > 1:
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', device))
+        else:
+            dist.init_process_group(args.backend)
 
     W, H, spp = args.width, args.height, args.spp
     detail = args.detail if args.detail is not None else util.ATRIUM_DETAIL
@@ -79,7 +85,7 @@ def main():
     util.SCRATCH = os.path.join(ROOT, 'tests', '_scratch', 'rank%d' % rank)
     bundle = util.atrium(detail=detail)
     P = scenes.atrium_params(ptamd.default_params(W, H))
-    r = bundle.renderer(P, local_rank, pack_textures=not args.fp32_textures)
+    r = bundle.renderer(P, device, pack_textures=not args.fp32_textures)
     r.set_max_bounces(args.bounces)
     r.set_mode(0 if args.mode == 'wavefront' else 1)
     if args.pool:
