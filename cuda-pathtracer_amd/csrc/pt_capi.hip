@@ -712,8 +712,12 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
         HIP_TRY(hipMemsetAsync(c->wf_counters, 0, WF_CTR_WORDS * sizeof(uint32_t), c->stream));
         launch_wf_generate(w, cam, ctr, c->stream);
         HIP_TRY(hipGetLastError());
-        const int batch = 8;
-        if (c->stage_timing && !c->st_ev[0]) { for (int i = 0; i < 2 * batch; i++) HIP_TRY(hipEventCreate(&c->st_ev[i])); }
+        // The host looks at the counters after every batch of iterations: 8 while new samples are still being
+        // started (a look costs a stream synchronisation), 2 once all are in flight, so that the hand-over to the
+        // drain kernel comes soon after the pool has thinned out.
+        const int max_batch = 8;
+        int batch = (size_t)w.n_slots >= (size_t)w.n_samples ? 2 : max_batch;
+        if (c->stage_timing && !c->st_ev[0]) { for (int i = 0; i < 2 * max_batch; i++) HIP_TRY(hipEventCreate(&c->st_ev[i])); }
         for (;;) {
             for (int i = 0; i < batch; i++)
                 launch_wf_iteration(w, c->scene, cam, ctr, c->stream, c->stage_timing ? c->st_ev[2 * i] : nullptr, c->stage_timing ? c->st_ev[2 * i + 1] : nullptr);
@@ -724,6 +728,7 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
             if (c->stage_timing) {
                 for (int i = 0; i < batch; i++) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->st_ev[2 * i], c->st_ev[2 * i + 1]) == hipSuccess) { c->extend_ms += ms; c->extend_launches++; } }
             }
+            if (c->wf_host_counters[WF_CTR_NEXT_SAMPLE] >= w.n_samples) batch = 2;
             if (c->wf_host_counters[WF_CTR_LIVE] == 0) break;
             // all sample ids handed out and few paths left: finish them in one kernel instead of one stage
             // launch sequence per remaining path vertex

@@ -9,6 +9,8 @@ b = util.atrium()
 W, H, n = 1920, 1080, 64
 P = scenes.atrium_params(ptamd.default_params(W, H))
 r = b.renderer(P)
+if os.environ.get('DRAIN'):
+    r.set_drain(int(os.environ['DRAIN']))
 r.enable_counters(True); r.render(P, 0, n); rays = r.counters()['rays']; r.enable_counters(False)
 for f in range(4):
     P.frameIndex = f; r.render_frame(P)
