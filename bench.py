@@ -52,6 +52,7 @@ def main():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl is RCCL; gloo lets several ranks rehearse on one GPU)')
     ap.add_argument('--device', type=int, default=-1, help='GPU to use (default: LOCAL_RANK)')
     ap.add_argument('--fp32-textures', action='store_true', help='keep 8-bit textures as fp32 texels instead of bytes')
+    ap.add_argument('--lanes', type=int, default=0, help='concurrent wavefront lanes (0 = library default)')
     ap.add_argument('--drain', type=int, default=-1, help='finish the last paths in one kernel once at most this many remain (-1 = library default, 0 = never)')
     ap.add_argument('--node-width', type=int, default=4, help='4-wide or binary (2) compact nodes in the traversal kernel')
     ap.add_argument('--tune', type=str, default='', help='refill_lanes,leaf_vote,blocks_per_cu for the traversal kernel')
@@ -93,6 +94,8 @@ def main():
     r.set_node_width(args.node_width)
     if args.drain >= 0:
         r.set_drain(args.drain)
+    if args.lanes:
+        r.set_lanes(args.lanes)
     if args.tune:
         r.set_extend_tuning(*[int(x) for x in args.tune.split(',')])
     stream = torch.cuda.current_stream()

@@ -68,16 +68,31 @@ struct pt_ctx {
     int mode = PT_MODE_WAVEFRONT;
     int pool_slots = 1 << 24;
     int chunk_frames = 64;
-    int refill_lanes = 8, leaf_vote = 12, extend_blocks_per_cu = 5, n_cus = 256;
-    void* wf_block = nullptr;       // one allocation holding every slot array
-    size_t wf_block_bytes = 0;
-    float* wf_staging = nullptr;
-    size_t wf_staging_bytes = 0;
-    uint32_t* wf_counters = nullptr;
-    uint32_t* wf_host_counters = nullptr;   // pinned
+    int refill_lanes = 8, leaf_vote = 12, n_cus = 256;
+    int extend_blocks_per_cu = 0;   // 0: 5 with one lane (all the LDS), 3 with two (room for the other lane's kernels)
+    // The wavefront loop runs as up to two independent lanes, each with its own slot pool, staging array,
+    // counters and stream, on disjoint frame ranges of a chunk: while one lane's traversal kernel (ALU bound)
+    // runs, the other lane's shading kernels (memory bound) can share the GPU.
+    struct WfLane {
+        hipStream_t stream = nullptr;   // lane 0 runs on the context's stream, the others on their own
+        void* block = nullptr;          // one allocation holding every slot array
+        size_t block_bytes = 0;
+        float* staging = nullptr;
+        size_t staging_bytes = 0;
+        uint32_t* counters = nullptr;
+        uint32_t* host_counters = nullptr;   // pinned
+        hipEvent_t st_ev[16] = {};
+        hipEvent_t ready = nullptr;     // the last issued batch and its counter copy are done
+        WfParams w{};
+        int batch = 8;
+        bool finished = true;
+    };
+    static constexpr int kMaxLanes = 2;
+    WfLane lanes[kMaxLanes];
+    int n_lanes = 2;
+    hipEvent_t ev_fork = nullptr;
     uint64_t wf_iterations = 0;
     bool stage_timing = false;
-    hipEvent_t st_ev[16] = {};
     double extend_ms = 0.0;
     uint64_t extend_launches = 0;
 };
@@ -133,7 +148,6 @@ void pt_destroy(pt_ctx* c)
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_tex) (void)hipFree(c->d_tex);
     for (void* p : c->tex_data) (void)hipFree(p);
-    for (hipEvent_t e : c->st_ev) if (e) (void)hipEventDestroy(e);
     if (c->d_env) (void)hipFree(c->d_env);
     if (c->d_cdf) (void)hipFree(c->d_cdf);
     if (c->d_env_tables) (void)hipFree(c->d_env_tables);
@@ -141,10 +155,17 @@ void pt_destroy(pt_ctx* c)
     if (c->own_accum) (void)hipFree(c->own_accum);
     if (c->display) (void)hipFree(c->display);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
-    if (c->wf_block) (void)hipFree(c->wf_block);
-    if (c->wf_staging) (void)hipFree(c->wf_staging);
-    if (c->wf_counters) (void)hipFree(c->wf_counters);
-    if (c->wf_host_counters) (void)hipHostFree(c->wf_host_counters);
+    for (int i = 0; i < pt_ctx::kMaxLanes; i++) {
+        pt_ctx::WfLane& L = c->lanes[i];
+        for (hipEvent_t e : L.st_ev) if (e) (void)hipEventDestroy(e);
+        if (L.ready) (void)hipEventDestroy(L.ready);
+        if (L.block) (void)hipFree(L.block);
+        if (L.staging) (void)hipFree(L.staging);
+        if (L.counters) (void)hipFree(L.counters);
+        if (L.host_counters) (void)hipHostFree(L.host_counters);
+        if (i > 0 && L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -651,32 +672,30 @@ static int fetch_counters(pt_ctx* c)
     return PT_OK;
 }
 
-// Sizes the slot pool and the staging array for a render of `frames` frames.
-static int wf_prepare(pt_ctx* c, int frames, WfParams* w)
+static int lane_counters(pt_ctx::WfLane& L)
 {
-    size_t npix = (size_t)c->W * c->H;
-    size_t n_samples = npix * (size_t)frames;
-    size_t slots = n_samples < (size_t)c->pool_slots ? n_samples : (size_t)c->pool_slots;
-    slots = (slots + 255) / 256 * 256;
+    if (!L.counters) {
+        HIP_TRY(hipMalloc((void**)&L.counters, WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipMemset(L.counters, 0, WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long)));
+        HIP_TRY(hipHostMalloc((void**)&L.host_counters, WF_CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    }
+    if (!L.ready) HIP_TRY(hipEventCreateWithFlags(&L.ready, hipEventDisableTiming));
+    return PT_OK;
+}
+
+// Lays the slot arrays of a lane out in its block (grown if needed) for `slots` slots.
+static int lane_pool(pt_ctx* c, pt_ctx::WfLane& L, size_t slots, WfParams* w)
+{
     size_t per_slot = 13 * sizeof(float4) + sizeof(uint32_t);
     size_t need = slots * per_slot + (slots / 256) * sizeof(uint32_t) + (slots / 64) * 2 * sizeof(uint32_t);
-    if (need > c->wf_block_bytes) {
-        if (c->wf_block) { (void)hipFree(c->wf_block); c->wf_block = nullptr; c->wf_block_bytes = 0; }
-        HIP_TRY(hipMalloc(&c->wf_block, need));
-        c->wf_block_bytes = need;
+    if (need > L.block_bytes) {
+        if (L.block) { (void)hipFree(L.block); L.block = nullptr; L.block_bytes = 0; }
+        HIP_TRY(hipMalloc(&L.block, need));
+        L.block_bytes = need;
     }
-    size_t sbytes = n_samples * sizeof(float);
-    if (sbytes > c->wf_staging_bytes) {
-        if (c->wf_staging) { (void)hipFree(c->wf_staging); c->wf_staging = nullptr; c->wf_staging_bytes = 0; }
-        HIP_TRY(hipMalloc((void**)&c->wf_staging, sbytes));
-        c->wf_staging_bytes = sbytes;
-    }
-    if (!c->wf_counters) {
-        HIP_TRY(hipMalloc((void**)&c->wf_counters, WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(c->wf_counters, 0, WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long)));
-        HIP_TRY(hipHostMalloc((void**)&c->wf_host_counters, WF_CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-    }
-    float4* base = (float4*)c->wf_block;
+    int rc = lane_counters(L);
+    if (rc != PT_OK) return rc;
+    float4* base = (float4*)L.block;
     float4** arrays[13] = {&w->ray_o, &w->ray_d, &w->hit, &w->c0, &w->c1, &w->c2, &w->d0, &w->d1, &w->e0, &w->e1, &w->e2, &w->e3, &w->e4};
     for (int i = 0; i < 13; i++) *arrays[i] = base + (size_t)i * slots;
     w->bsdf_queue = (uint32_t*)(base + (size_t)13 * slots);
@@ -684,62 +703,123 @@ static int wf_prepare(pt_ctx* c, int frames, WfParams* w)
     w->block_chunk = w->bsdf_count + slots / 256;
     w->chunk_rays = w->block_chunk + 2 * (slots / 256);
     w->chunk_list = w->chunk_rays + slots / 256;
-    w->counters = c->wf_counters;
-    w->staging = c->wf_staging;
+    w->counters = L.counters;
     w->n_slots = (int)slots;
+    w->refill_lanes = c->refill_lanes; w->leaf_vote = c->leaf_vote;
+    w->extend_blocks = (c->extend_blocks_per_cu ? c->extend_blocks_per_cu : (c->n_lanes > 1 ? 3 : 5)) * c->n_cus;
+    return PT_OK;
+}
+
+// Sizes a lane's slot pool and staging array for a render of `frames` frames.
+static int wf_prepare(pt_ctx* c, pt_ctx::WfLane& L, int frames, size_t pool_slots, WfParams* w)
+{
+    size_t npix = (size_t)c->W * c->H;
+    size_t n_samples = npix * (size_t)frames;
+    size_t slots = n_samples < pool_slots ? n_samples : pool_slots;
+    slots = (slots + 255) / 256 * 256;
+    int rc = lane_pool(c, L, slots, w);
+    if (rc != PT_OK) return rc;
+    size_t sbytes = n_samples * sizeof(float);
+    if (sbytes > L.staging_bytes) {
+        if (L.staging) { (void)hipFree(L.staging); L.staging = nullptr; L.staging_bytes = 0; }
+        HIP_TRY(hipMalloc((void**)&L.staging, sbytes));
+        L.staging_bytes = sbytes;
+    }
+    w->staging = L.staging;
     w->n_samples = (uint32_t)n_samples;
     w->W = c->W; w->H = c->H;
     w->tiled = (c->W % 8 == 0 && c->H % 8 == 0) ? 1 : 0;
     w->n_frames = frames;
-    w->refill_lanes = c->refill_lanes; w->leaf_vote = c->leaf_vote;
-    w->extend_blocks = c->extend_blocks_per_cu * c->n_cus;
     return PT_OK;
 }
 
-// Frames [f0, f1) through the stage kernels, in chunks that bound the staging memory.
+// The host looks at a lane's counters after every batch of iterations: 8 while new samples are still being
+// started (a look costs a wait), 2 once all are in flight, so that the hand-over to the drain kernel comes
+// soon after the pool has thinned out.
+static const int kMaxBatch = 8;
+
+static int lane_issue_batch(pt_ctx* c, pt_ctx::WfLane& L, const DCamera& cam, DCounters* ctr)
+{
+    if (c->stage_timing && !L.st_ev[0]) { for (int i = 0; i < 2 * kMaxBatch; i++) HIP_TRY(hipEventCreate(&L.st_ev[i])); }
+    for (int i = 0; i < L.batch; i++)
+        launch_wf_iteration(L.w, c->scene, cam, ctr, L.stream, c->stage_timing ? L.st_ev[2 * i] : nullptr, c->stage_timing ? L.st_ev[2 * i + 1] : nullptr);
+    HIP_TRY(hipGetLastError());
+    c->wf_iterations += L.batch;
+    HIP_TRY(hipMemcpyAsync(L.host_counters, L.counters, WF_CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, L.stream));
+    HIP_TRY(hipEventRecord(L.ready, L.stream));
+    return PT_OK;
+}
+
+// Frames [f0, f1) through the stage kernels, in chunks that bound the staging memory. Within a chunk the
+// lanes take consecutive frame ranges; their staged samples are added to the accumulator in lane order on
+// the context's stream, so the additions happen in frame order whatever the lanes' timing was.
 static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
 {
     size_t npix = (size_t)c->W * c->H;
     int max_chunk = c->chunk_frames;
     while (max_chunk > 1 && npix * (size_t)max_chunk > ((size_t)1 << 30)) max_chunk /= 2;     // at most 2^30 samples (4 GiB of staging)
     DCounters* ctr = c->counting ? c->d_ctr : nullptr;
+    if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    c->lanes[0].stream = c->stream;
+    for (int i = 1; i < pt_ctx::kMaxLanes; i++)
+        if (!c->lanes[i].stream) HIP_TRY(hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking));
     for (int b = f0; b < f1; b += max_chunk) {
         int frames = (f1 - b) < max_chunk ? (f1 - b) : max_chunk;
-        WfParams w{};
-        int rc = wf_prepare(c, frames, &w);
-        if (rc != PT_OK) return rc;
-        w.frame_begin = b;
-        HIP_TRY(hipMemsetAsync(c->wf_counters, 0, WF_CTR_WORDS * sizeof(uint32_t), c->stream));
-        launch_wf_generate(w, cam, ctr, c->stream);
-        HIP_TRY(hipGetLastError());
-        // The host looks at the counters after every batch of iterations: 8 while new samples are still being
-        // started (a look costs a stream synchronisation), 2 once all are in flight, so that the hand-over to the
-        // drain kernel comes soon after the pool has thinned out.
-        const int max_batch = 8;
-        int batch = (size_t)w.n_slots >= (size_t)w.n_samples ? 2 : max_batch;
-        if (c->stage_timing && !c->st_ev[0]) { for (int i = 0; i < 2 * max_batch; i++) HIP_TRY(hipEventCreate(&c->st_ev[i])); }
-        for (;;) {
-            for (int i = 0; i < batch; i++)
-                launch_wf_iteration(w, c->scene, cam, ctr, c->stream, c->stage_timing ? c->st_ev[2 * i] : nullptr, c->stage_timing ? c->st_ev[2 * i + 1] : nullptr);
+        int n_lanes = c->n_lanes < frames ? c->n_lanes : frames;
+        size_t lane_pool_slots = (size_t)c->pool_slots / (size_t)n_lanes;
+        if (lane_pool_slots < 256) lane_pool_slots = 256;
+        // the other lanes start after everything queued on the context's stream so far (uploads, the previous
+        // chunk's accumulation, which reads their staging arrays)
+        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        int fb = b;
+        for (int i = 0; i < n_lanes; i++) {
+            pt_ctx::WfLane& L = c->lanes[i];
+            int fr = frames * (i + 1) / n_lanes - frames * i / n_lanes;
+            if (i > 0) HIP_TRY(hipStreamWaitEvent(L.stream, c->ev_fork, 0));
+            int rc = wf_prepare(c, L, fr, lane_pool_slots, &L.w);
+            if (rc != PT_OK) return rc;
+            L.w.frame_begin = fb;
+            fb += fr;
+            HIP_TRY(hipMemsetAsync(L.counters, 0, WF_CTR_WORDS * sizeof(uint32_t), L.stream));
+            launch_wf_generate(L.w, cam, ctr, L.stream);
             HIP_TRY(hipGetLastError());
-            c->wf_iterations += batch;
-            HIP_TRY(hipMemcpyAsync(c->wf_host_counters, c->wf_counters, WF_CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(hipStreamSynchronize(c->stream));
-            if (c->stage_timing) {
-                for (int i = 0; i < batch; i++) { float ms = 0.f; if (hipEventElapsedTime(&ms, c->st_ev[2 * i], c->st_ev[2 * i + 1]) == hipSuccess) { c->extend_ms += ms; c->extend_launches++; } }
-            }
-            if (c->wf_host_counters[WF_CTR_NEXT_SAMPLE] >= w.n_samples) batch = 2;
-            if (c->wf_host_counters[WF_CTR_LIVE] == 0) break;
-            // all sample ids handed out and few paths left: finish them in one kernel instead of one stage
-            // launch sequence per remaining path vertex
-            if (c->drain_rays > 0 && c->wf_host_counters[WF_CTR_NEXT_SAMPLE] >= w.n_samples && c->wf_host_counters[WF_CTR_RAYS] <= (uint32_t)c->drain_rays) {
-                launch_wf_drain(w, c->scene, cam, (int)c->wf_host_counters[WF_CTR_RAYS], ctr, c->stream);
-                HIP_TRY(hipGetLastError());
-                break;
+            L.batch = (size_t)L.w.n_slots >= (size_t)L.w.n_samples ? 2 : kMaxBatch;
+            L.finished = false;
+            rc = lane_issue_batch(c, L, cam, ctr);
+            if (rc != PT_OK) return rc;
+        }
+        for (int remaining = n_lanes; remaining > 0;) {
+            for (int i = 0; i < n_lanes; i++) {
+                pt_ctx::WfLane& L = c->lanes[i];
+                if (L.finished) continue;
+                HIP_TRY(hipEventSynchronize(L.ready));
+                if (c->stage_timing) {
+                    for (int k = 0; k < L.batch; k++) { float ms = 0.f; if (hipEventElapsedTime(&ms, L.st_ev[2 * k], L.st_ev[2 * k + 1]) == hipSuccess) { c->extend_ms += ms; c->extend_launches++; } }
+                }
+                const uint32_t* hc = L.host_counters;
+                if (hc[WF_CTR_NEXT_SAMPLE] >= L.w.n_samples) L.batch = 2;
+                if (hc[WF_CTR_LIVE] == 0) { L.finished = true; remaining--; continue; }
+                // all sample ids handed out and few paths left: finish them in one kernel instead of one stage
+                // launch sequence per remaining path vertex
+                if (c->drain_rays > 0 && hc[WF_CTR_NEXT_SAMPLE] >= L.w.n_samples && hc[WF_CTR_RAYS] <= (uint32_t)c->drain_rays) {
+                    launch_wf_drain(L.w, c->scene, cam, (int)hc[WF_CTR_RAYS], ctr, L.stream);
+                    HIP_TRY(hipGetLastError());
+                    L.finished = true; remaining--;
+                    continue;
+                }
+                int rc = lane_issue_batch(c, L, cam, ctr);
+                if (rc != PT_OK) return rc;
             }
         }
-        launch_wf_accumulate(w, cam, c->accum, c->stream);
-        HIP_TRY(hipGetLastError());
+        for (int i = 0; i < n_lanes; i++) {
+            pt_ctx::WfLane& L = c->lanes[i];
+            if (i > 0) {
+                HIP_TRY(hipEventRecord(L.ready, L.stream));
+                HIP_TRY(hipStreamWaitEvent(c->stream, L.ready, 0));
+            }
+            launch_wf_accumulate(L.w, cam, c->accum, c->stream);
+            HIP_TRY(hipGetLastError());
+        }
     }
     return PT_OK;
 }
@@ -757,9 +837,16 @@ int pt_stage_timing(pt_ctx* c, int on, double* extend_ms_out, uint64_t* extend_l
 // diagnostic builds only: the 16 debug words the extend kernel accumulates (zeroed on read)
 int pt_debug_words(pt_ctx* c, unsigned long long* out16)
 {
-    if (!c || !out16 || !c->wf_counters) { set_error("pt_debug_words: nothing to read"); return PT_ERR_STATE; }
-    HIP_TRY(hipMemcpy(out16, c->wf_counters + WF_CTR_WORDS, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemset(c->wf_counters + WF_CTR_WORDS, 0, 16 * sizeof(unsigned long long)));
+    if (!c || !out16 || !c->lanes[0].counters) { set_error("pt_debug_words: nothing to read"); return PT_ERR_STATE; }
+    HIP_TRY(hipDeviceSynchronize());
+    for (int k = 0; k < 16; k++) out16[k] = 0;
+    for (int i = 0; i < pt_ctx::kMaxLanes; i++) {
+        if (!c->lanes[i].counters) continue;
+        unsigned long long part[16];
+        HIP_TRY(hipMemcpy(part, c->lanes[i].counters + WF_CTR_WORDS, sizeof(part), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(c->lanes[i].counters + WF_CTR_WORDS, 0, sizeof(part)));
+        for (int k = 0; k < 16; k++) out16[k] += part[k];
+    }
     return PT_OK;
 }
 
@@ -783,6 +870,13 @@ int pt_set_mode(pt_ctx* c, int mode)
 {
     if (!c || (mode != PT_MODE_WAVEFRONT && mode != PT_MODE_SINGLE_KERNEL)) { set_error("pt_set_mode: bad argument"); return PT_ERR_ARG; }
     c->mode = mode;
+    return PT_OK;
+}
+
+int pt_set_lanes(pt_ctx* c, int lanes)
+{
+    if (!c || lanes < 1 || lanes > pt_ctx::kMaxLanes) { set_error("pt_set_lanes: 1 or 2 lanes"); return PT_ERR_ARG; }
+    c->n_lanes = lanes;
     return PT_OK;
 }
 
@@ -938,27 +1032,12 @@ int pt_trace_closest_fast_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* 
     if (rc != PT_OK) return rc;
     if (n <= 0 || !rays_dev || !hits_dev) { set_error("pt_trace_closest_fast_dev: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
-    // borrow the pool's ray and hit arrays
+    // borrow lane 0's ray and hit arrays
     size_t slots = ((size_t)n + 255) / 256 * 256;
-    size_t need = slots * (13 * sizeof(float4) + sizeof(uint32_t)) + (slots / 256) * sizeof(uint32_t) + (slots / 64) * 2 * sizeof(uint32_t);
-    if (need > c->wf_block_bytes) {
-        if (c->wf_block) { (void)hipFree(c->wf_block); c->wf_block = nullptr; c->wf_block_bytes = 0; }
-        HIP_TRY(hipMalloc(&c->wf_block, need));
-        c->wf_block_bytes = need;
-    }
-    if (!c->wf_counters) {
-        HIP_TRY(hipMalloc((void**)&c->wf_counters, WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long)));
-        HIP_TRY(hipMemset(c->wf_counters, 0, WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long)));
-        HIP_TRY(hipHostMalloc((void**)&c->wf_host_counters, WF_CTR_WORDS * sizeof(uint32_t), hipHostMallocDefault));
-    }
     WfParams w{};
-    float4* base = (float4*)c->wf_block;
-    w.ray_o = base; w.ray_d = base + slots; w.hit = base + 2 * slots;
-    w.chunk_rays = (uint32_t*)(base + (size_t)13 * slots) + slots + slots / 256 + 2 * (slots / 256);
-    w.chunk_list = w.chunk_rays + slots / 256;
-    w.counters = c->wf_counters;
-    w.n_slots = (int)slots;
-    w.refill_lanes = c->refill_lanes; w.leaf_vote = c->leaf_vote; w.extend_blocks = c->extend_blocks_per_cu * c->n_cus;
+    rc = lane_pool(c, c->lanes[0], slots, &w);
+    if (rc != PT_OK) return rc;
+    if (!c->extend_blocks_per_cu) w.extend_blocks = 5 * c->n_cus;      // nothing runs beside this batch
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     launch_wf_trace(w, c->scene, rays_dev, n, hits_dev, c->stream);
     HIP_TRY(hipGetLastError());

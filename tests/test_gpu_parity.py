@@ -473,3 +473,21 @@ def test_guided_environment_search_is_the_bisection():
     r.render(P, 0, 3)
     _assert_radiance(r.read_accum(), want)
     r.close()
+
+
+def test_one_and_two_lanes_agree_and_odd_frame_counts():
+    """Two concurrent lanes split every chunk of frames; one lane, two lanes, and frame counts that do not divide
+    evenly (or are smaller than the lane count) all give the oracle's accumulator."""
+    b = util.atrium(detail=0.3, env_size=(64, 32))
+    P = scenes.atrium_params(ptamd.default_params(72, 40))
+    want, st = orc.render(b.oracle(P), P, 2, 9, 12)
+    for lanes, pool in ((1, (4096, 3)), (2, (4096, 3)), (2, (1 << 20, 64)), (2, (700, 1))):
+        r = b.renderer(P)
+        r.set_lanes(lanes)
+        r.set_pool(*pool)
+        r.set_max_bounces(12)
+        r.enable_counters(True)
+        r.render(P, 2, 9)
+        _assert_radiance(r.read_accum(), want)
+        assert r.counters()['rays'] == st['rays'] and r.counters()['samples'] == st['samples']
+        r.close()
