@@ -68,7 +68,7 @@ struct pt_ctx {
     int mode = PT_MODE_WAVEFRONT;
     int pool_slots = 1 << 24;
     int chunk_frames = 64;
-    int refill_lanes = 8, leaf_vote = 12, n_cus = 256;
+    int refill_lanes = 12, leaf_vote = 16, n_cus = 256;
     int extend_blocks_per_cu = 0;   // 0: 5 with one lane (all the LDS), 3 with two (room for the other lane's kernels)
     // The wavefront loop runs as up to two independent lanes, each with its own slot pool, staging array,
     // counters and stream, on disjoint frame ranges of a chunk: while one lane's traversal kernel (ALU bound)
