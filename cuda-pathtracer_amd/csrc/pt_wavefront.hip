@@ -556,7 +556,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
 // ---------------------------------------------------------------- shade
 template <bool COUNT>
 #ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 4
+#define PT_SHADE_WAVES 3
 #endif
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES))) void wf_shade_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
