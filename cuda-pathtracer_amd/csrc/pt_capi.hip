@@ -476,9 +476,22 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
 int pt_build_bvh(pt_ctx* c, int flavour)
 {
     if (!c || !c->have_tris) { set_error("pt_build_bvh: upload triangles first"); return PT_ERR_STATE; }
-    if (flavour != PT_BVH_REFERENCE) { set_error("pt_build_bvh: unknown flavour %d", flavour); return PT_ERR_ARG; }
+    if (flavour != PT_BVH_REFERENCE && flavour != PT_BVH_GPU_LBVH) { set_error("pt_build_bvh: unknown flavour %d", flavour); return PT_ERR_ARG; }
     int n = (int)c->tris.size();
     std::vector<pt_bvh_node> nodes((size_t)2 * n - 1 + 1);
+    if (flavour == PT_BVH_GPU_LBVH) {
+        HIP_TRY(hipSetDevice(c->device));
+        pt_bvh_node* d_nodes = nullptr;
+        int* d_idx = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_nodes, ((size_t)2 * n - 1) * sizeof(pt_bvh_node)));
+        if (hipMalloc((void**)&d_idx, (size_t)n * sizeof(int)) != hipSuccess) { (void)hipFree(d_nodes); set_error("pt_build_bvh: out of device memory"); return PT_ERR_NOMEM; }
+        int rc = gpu_build_lbvh(c->d_tri_ref, n, d_nodes, d_idx, c->stream);
+        if (rc == PT_OK && hipMemcpy(nodes.data(), d_nodes, ((size_t)2 * n - 1) * sizeof(pt_bvh_node), hipMemcpyDeviceToHost) != hipSuccess) { set_error("pt_build_bvh: copy failed"); rc = PT_ERR_HIP; }
+        if (rc == PT_OK && hipMemcpy(c->tri_idx.data(), d_idx, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { set_error("pt_build_bvh: copy failed"); rc = PT_ERR_HIP; }
+        (void)hipFree(d_nodes); (void)hipFree(d_idx);
+        if (rc != PT_OK) return rc;
+        return pt_upload_bvh(c, nodes.data(), 0, 2 * n - 1, n);
+    }
     for (int i = 0; i < n; i++) c->tri_idx[i] = i;
     int used = 0;
     int rc = build_bvh_reference(c->tris.data(), c->tri_idx.data(), n, nodes.data(), &used);

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get('PTAMD_LIB') or os.path.join(_PKG, 'libptamd.so')     
 
 PT_SKY_ENVMAP, PT_SKY_SUNSKY = 0, 1
 PT_BVH_REFERENCE = 0
+PT_BVH_GPU_LBVH = 1
 PT_MODE_WAVEFRONT, PT_MODE_SINGLE_KERNEL = 0, 1
 
 EXPORTS = [
@@ -196,14 +197,14 @@ class Renderer:
         check(lib().pt_upload_texture(self.h, _p(t), C.c_int(w), C.c_int(h), C.c_int(c), C.byref(handle)))
         return handle.value
 
-    def upload_scene(self, tris, mats, tri_idx=None, nodes=None):
+    def upload_scene(self, tris, mats, tri_idx=None, nodes=None, flavour=PT_BVH_REFERENCE):
         tris = np.ascontiguousarray(tris, dtype=TRI_DTYPE)
         mats = np.ascontiguousarray(mats, dtype=MAT_DTYPE)
         idx = None if tri_idx is None else np.ascontiguousarray(tri_idx, dtype=np.int32)
         check(lib().pt_upload_triangles(self.h, _p(idx), _p(tris), C.c_int(len(tris))))
         check(lib().pt_upload_materials(self.h, _p(mats), C.c_int(len(mats))))
         if nodes is None:
-            check(lib().pt_build_bvh(self.h, C.c_int(PT_BVH_REFERENCE)))
+            check(lib().pt_build_bvh(self.h, C.c_int(flavour)))
         else:
             nodes = np.ascontiguousarray(nodes, dtype=NODE_DTYPE)
             check(lib().pt_upload_bvh(self.h, _p(nodes), C.c_int(0), C.c_int(len(nodes)), C.c_int(len(tris))))

@@ -41,6 +41,7 @@ extern "C" {
 
 /* BVH build flavours for pt_host_build_bvh / pt_build_bvh */
 #define PT_BVH_REFERENCE 0   /* identical tree to BVH_builder.cpp:12-128, built with binned sweeps */
+#define PT_BVH_GPU_LBVH  1   /* pt_build_bvh only: Morton-order radix tree built on the GPU in milliseconds; same images (closest hits do not depend on the tree), different test counters */
 
 typedef struct pt_float2 { float x, y; } pt_float2;
 typedef struct pt_float3 { float x, y, z; } pt_float3;

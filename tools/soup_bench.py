@@ -36,6 +36,14 @@ ref = r.trace_closest(rays[:500000])
 r.set_node_width(4)
 h = r.trace_closest_fast(rays[:500000])
 print('exact vs reference-order kernel:', bool(np.array_equal(h['tri'], ref['tri']) and np.array_equal(bits(h['t']), bits(ref['t']))), flush=True)
+t5 = time.time()
+r.upload_scene(tris, mats, None, None, flavour=lib.PT_BVH_GPU_LBVH)
+print('GPU LBVH: upload + build + flatten %.1f s' % (time.time() - t5), flush=True)
+r.set_node_width(4)
+h2 = r.trace_closest_fast(rays); h2 = r.trace_closest_fast(rays)
+ms = r.counters()['last_ms']
+print('LBVH tree: %.2f ms -> %.1f Mrays/s, same hits as the reference tree: %s' % (ms, len(rays) / ms / 1e3, bool(np.array_equal(h2['tri'], r.trace_closest_fast(rays)['tri']) and np.array_equal(h2['tri'][:500000], ref['tri']) and np.array_equal(bits(h2['t'][:500000]), bits(ref['t'])))), flush=True)
+r.upload_scene(tris, mats, idx, nodes)
 r.set_max_bounces(512)
 r.render(P, 0, 1)
 r.enable_counters(True); r.reset_counters(); r.render(P, 0, spp); c = r.counters(); r.enable_counters(False)
