@@ -69,7 +69,7 @@ struct pt_ctx {
     int pool_slots = 1 << 24;
     int chunk_frames = 64;
     int refill_lanes = 12, leaf_vote = 16, n_cus = 256;
-    int extend_blocks_per_cu = 0;   // 0: 5 with one lane (all the LDS), 3 with two (room for the other lane's kernels)
+    int extend_blocks_per_cu = 0;   // 0: 5 when one lane runs (all the LDS), 3 when two do
     // The wavefront loop runs as up to two independent lanes, each with its own slot pool, staging array,
     // counters and stream, on disjoint frame ranges of a chunk: while one lane's traversal kernel (ALU bound)
     // runs, the other lane's shading kernels (memory bound) can share the GPU.
@@ -90,6 +90,7 @@ struct pt_ctx {
     static constexpr int kMaxLanes = 2;
     WfLane lanes[kMaxLanes];
     int n_lanes = 2;
+    bool lanes_forced = false;      // pt_set_lanes was called: use that count whatever the render size
     hipEvent_t ev_fork = nullptr;
     uint64_t wf_iterations = 0;
     bool stage_timing = false;
@@ -719,19 +720,24 @@ static int lane_pool(pt_ctx* c, pt_ctx::WfLane& L, size_t slots, WfParams* w)
     w->counters = L.counters;
     w->n_slots = (int)slots;
     w->refill_lanes = c->refill_lanes; w->leaf_vote = c->leaf_vote;
-    w->extend_blocks = (c->extend_blocks_per_cu ? c->extend_blocks_per_cu : (c->n_lanes > 1 ? 3 : 5)) * c->n_cus;
+    w->extend_blocks = (c->extend_blocks_per_cu ? c->extend_blocks_per_cu : 5) * c->n_cus;
     return PT_OK;
 }
 
-// Sizes a lane's slot pool and staging array for a render of `frames` frames.
-static int wf_prepare(pt_ctx* c, pt_ctx::WfLane& L, int frames, size_t pool_slots, WfParams* w)
+// Sizes a lane's slot pool and staging array for `frames` frames of the pixels dealt to lane `lane` of `n_lanes`.
+static int wf_prepare(pt_ctx* c, pt_ctx::WfLane& L, int frames, int lane, int n_lanes, size_t pool_slots, WfParams* w)
 {
     size_t npix = (size_t)c->W * c->H;
-    size_t n_samples = npix * (size_t)frames;
+    size_t blocks = (npix + 63) / 64, rem = npix % 64;
+    size_t mine = (blocks - (size_t)lane + (size_t)n_lanes - 1) / (size_t)n_lanes;       // blocks lane, lane + n_lanes, ...
+    size_t n_pixels = mine * 64;
+    if (rem != 0 && (blocks - 1) % (size_t)n_lanes == (size_t)lane) n_pixels -= 64 - rem;    // the last block is short and it is ours
+    size_t n_samples = n_pixels * (size_t)frames;
     size_t slots = n_samples < pool_slots ? n_samples : pool_slots;
     slots = (slots + 255) / 256 * 256;
     int rc = lane_pool(c, L, slots, w);
     if (rc != PT_OK) return rc;
+    if (!c->extend_blocks_per_cu) w->extend_blocks = (n_lanes > 1 ? 3 : 5) * c->n_cus;     // room for the other lane's kernels
     size_t sbytes = n_samples * sizeof(float);
     if (sbytes > L.staging_bytes) {
         if (L.staging) { (void)hipFree(L.staging); L.staging = nullptr; L.staging_bytes = 0; }
@@ -740,6 +746,8 @@ static int wf_prepare(pt_ctx* c, pt_ctx::WfLane& L, int frames, size_t pool_slot
     }
     w->staging = L.staging;
     w->n_samples = (uint32_t)n_samples;
+    w->n_pixels = (uint32_t)n_pixels;
+    w->px_lane = lane; w->px_lanes = n_lanes;
     w->W = c->W; w->H = c->H;
     w->tiled = (c->W % 8 == 0 && c->H % 8 == 0) ? 1 : 0;
     w->n_frames = frames;
@@ -763,9 +771,9 @@ static int lane_issue_batch(pt_ctx* c, pt_ctx::WfLane& L, const DCamera& cam, DC
     return PT_OK;
 }
 
-// Frames [f0, f1) through the stage kernels, in chunks that bound the staging memory. Within a chunk the
-// lanes take consecutive frame ranges; their staged samples are added to the accumulator in lane order on
-// the context's stream, so the additions happen in frame order whatever the lanes' timing was.
+// Frames [f0, f1) through the stage kernels, in chunks that bound the staging memory. The lanes own disjoint
+// pixels (blocks of 64 dealt in turn) and each adds its staged samples to its pixels frame by frame, so every
+// pixel sees its additions in frame order whatever the lanes' timing was.
 static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
 {
     size_t npix = (size_t)c->W * c->H;
@@ -776,23 +784,23 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
     c->lanes[0].stream = c->stream;
     for (int i = 1; i < pt_ctx::kMaxLanes; i++)
         if (!c->lanes[i].stream) HIP_TRY(hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking));
+    size_t pixel_blocks = (npix + 63) / 64;
     for (int b = f0; b < f1; b += max_chunk) {
         int frames = (f1 - b) < max_chunk ? (f1 - b) : max_chunk;
-        int n_lanes = c->n_lanes < frames ? c->n_lanes : frames;
+        // a second lane pays from about three million samples on (measured: a 1080p frame is faster on one lane,
+        // two frames on two); the split never changes a result, so small renders may use any count
+        int n_lanes = (size_t)c->n_lanes < pixel_blocks ? c->n_lanes : (int)pixel_blocks;
+        if (!c->lanes_forced && npix * (size_t)frames < ((size_t)3 << 20)) n_lanes = 1;
         size_t lane_pool_slots = (size_t)c->pool_slots / (size_t)n_lanes;
         if (lane_pool_slots < 256) lane_pool_slots = 256;
-        // the other lanes start after everything queued on the context's stream so far (uploads, the previous
-        // chunk's accumulation, which reads their staging arrays)
+        // the other lanes start after everything queued on the context's stream so far (uploads, earlier renders)
         HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
-        int fb = b;
         for (int i = 0; i < n_lanes; i++) {
             pt_ctx::WfLane& L = c->lanes[i];
-            int fr = frames * (i + 1) / n_lanes - frames * i / n_lanes;
             if (i > 0) HIP_TRY(hipStreamWaitEvent(L.stream, c->ev_fork, 0));
-            int rc = wf_prepare(c, L, fr, lane_pool_slots, &L.w);
+            int rc = wf_prepare(c, L, frames, i, n_lanes, lane_pool_slots, &L.w);
             if (rc != PT_OK) return rc;
-            L.w.frame_begin = fb;
-            fb += fr;
+            L.w.frame_begin = b;
             HIP_TRY(hipMemsetAsync(L.counters, 0, WF_CTR_WORDS * sizeof(uint32_t), L.stream));
             launch_wf_generate(L.w, cam, ctr, L.stream);
             HIP_TRY(hipGetLastError());
@@ -811,11 +819,16 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
                 }
                 const uint32_t* hc = L.host_counters;
                 if (hc[WF_CTR_NEXT_SAMPLE] >= L.w.n_samples) L.batch = 2;
-                if (hc[WF_CTR_LIVE] == 0) { L.finished = true; remaining--; continue; }
+                bool done = hc[WF_CTR_LIVE] == 0;
                 // all sample ids handed out and few paths left: finish them in one kernel instead of one stage
                 // launch sequence per remaining path vertex
-                if (c->drain_rays > 0 && hc[WF_CTR_NEXT_SAMPLE] >= L.w.n_samples && hc[WF_CTR_RAYS] <= (uint32_t)c->drain_rays) {
+                if (!done && c->drain_rays > 0 && hc[WF_CTR_NEXT_SAMPLE] >= L.w.n_samples && hc[WF_CTR_RAYS] <= (uint32_t)c->drain_rays) {
                     launch_wf_drain(L.w, c->scene, cam, (int)hc[WF_CTR_RAYS], ctr, L.stream);
+                    HIP_TRY(hipGetLastError());
+                    done = true;
+                }
+                if (done) {
+                    launch_wf_accumulate(L.w, cam, c->accum, L.stream);
                     HIP_TRY(hipGetLastError());
                     L.finished = true; remaining--;
                     continue;
@@ -824,14 +837,10 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
                 if (rc != PT_OK) return rc;
             }
         }
-        for (int i = 0; i < n_lanes; i++) {
-            pt_ctx::WfLane& L = c->lanes[i];
-            if (i > 0) {
-                HIP_TRY(hipEventRecord(L.ready, L.stream));
-                HIP_TRY(hipStreamWaitEvent(c->stream, L.ready, 0));
-            }
-            launch_wf_accumulate(L.w, cam, c->accum, c->stream);
-            HIP_TRY(hipGetLastError());
+        // the context's stream continues after the other lanes
+        for (int i = 1; i < n_lanes; i++) {
+            HIP_TRY(hipEventRecord(c->lanes[i].ready, c->lanes[i].stream));
+            HIP_TRY(hipStreamWaitEvent(c->stream, c->lanes[i].ready, 0));
         }
     }
     return PT_OK;
@@ -890,6 +899,7 @@ int pt_set_lanes(pt_ctx* c, int lanes)
 {
     if (!c || lanes < 1 || lanes > pt_ctx::kMaxLanes) { set_error("pt_set_lanes: 1 or 2 lanes"); return PT_ERR_ARG; }
     c->n_lanes = lanes;
+    c->lanes_forced = true;
     return PT_OK;
 }
 
@@ -1050,7 +1060,6 @@ int pt_trace_closest_fast_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* 
     WfParams w{};
     rc = lane_pool(c, c->lanes[0], slots, &w);
     if (rc != PT_OK) return rc;
-    if (!c->extend_blocks_per_cu) w.extend_blocks = 5 * c->n_cus;      // nothing runs beside this batch
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     launch_wf_trace(w, c->scene, rays_dev, n, hits_dev, c->stream);
     HIP_TRY(hipGetLastError());

@@ -130,6 +130,10 @@ struct WfParams {
     int n_slots;
     uint32_t n_samples;
     int W, H, tiled, frame_begin, n_frames;
+    // The pixels of the image, in sample order (8x8 tiles when the size allows, else rows), are dealt to the lanes in
+    // blocks of 64: this lane owns blocks px_lane, px_lane + px_lanes, ...; n_pixels of them in all.
+    int px_lane, px_lanes;
+    uint32_t n_pixels;
     int refill_lanes, leaf_vote, extend_blocks;   // extend-kernel tuning (see wf_extend_kernel)
 };
 

@@ -46,25 +46,31 @@ PT_DEV void unpack_flags(Path& P, uint32_t f)
 
 struct SampleId { int x, y, frame; uint32_t pixel; uint32_t stage_index; };
 
-// sample id -> (pixel, frame). Pixels are walked in 8x8 tiles when the image allows it, so that the
-// 64 samples a wave takes together form one tile (coherent camera rays), else row by row.
-PT_DEV SampleId decode_sample(const WfParams& w, uint32_t s)
+// Position of a lane-local pixel number in the image. Pixels are walked in 8x8 tiles when the image allows it,
+// so that the 64 samples a wave takes together form one tile (coherent camera rays), else row by row; blocks of
+// 64 consecutive pixels of that order are dealt to the lanes in turn.
+PT_DEV void lane_pixel(const WfParams& w, uint32_t q, int& x, int& y)
 {
-    SampleId id;
-    uint32_t npix = (uint32_t)(w.W * w.H);
-    uint32_t fr = s / npix, p = s - fr * npix;
+    uint32_t p = ((q >> 6) * (uint32_t)w.px_lanes + (uint32_t)w.px_lane) * 64u + (q & 63u);
     if (w.tiled) {
         uint32_t tiles_x = (uint32_t)w.W >> 3;
         uint32_t tile = p >> 6, l = p & 63u;
-        id.x = (int)((tile % tiles_x) * 8 + (l & 7u));
-        id.y = (int)((tile / tiles_x) * 8 + (l >> 3));
+        x = (int)((tile % tiles_x) * 8 + (l & 7u));
+        y = (int)((tile / tiles_x) * 8 + (l >> 3));
     } else {
-        id.x = (int)(p % (uint32_t)w.W);
-        id.y = (int)(p / (uint32_t)w.W);
+        x = (int)(p % (uint32_t)w.W);
+        y = (int)(p / (uint32_t)w.W);
     }
+}
+// sample id -> (pixel, frame): the lane's pixels frame after frame
+PT_DEV SampleId decode_sample(const WfParams& w, uint32_t s)
+{
+    SampleId id;
+    uint32_t fr = s / w.n_pixels, q = s - fr * w.n_pixels;
+    lane_pixel(w, q, id.x, id.y);
     id.frame = w.frame_begin + (int)fr;
     id.pixel = (uint32_t)(id.x + id.y * w.W);
-    id.stage_index = fr * npix + id.pixel;
+    id.stage_index = s;
     return id;
 }
 
@@ -785,13 +791,15 @@ __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, 
 // re-derived from its random stream (draw 2, or 4 with the thin lens: pathtracer.cu:562,577,527).
 __global__ __launch_bounds__(kBlock) void wf_accumulate_kernel(WfParams w, DCamera cam, float* __restrict__ accum)
 {
-    uint32_t p = blockIdx.x * kBlock + threadIdx.x;
-    uint32_t npix = (uint32_t)(w.W * w.H);
-    if (p >= npix) return;
+    uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    if (q >= w.n_pixels) return;
+    int x, y;
+    lane_pixel(w, q, x, y);
+    uint32_t p = (uint32_t)(x + y * w.W);
     F3 acc = f3(accum[3 * (size_t)p], accum[3 * (size_t)p + 1], accum[3 * (size_t)p + 2]);
     uint32_t ch_draw = cam.dof > 0.f ? 4u : 2u;
     for (int f = 0; f < w.n_frames; f++) {
-        float v = w.staging[(size_t)f * npix + p];
+        float v = w.staging[(size_t)f * w.n_pixels + q];
         Rng g;
         rng_seed(g, p, (uint32_t)(w.frame_begin + f), ch_draw);
         int ch = int(rng_next(g) * 3.);
@@ -923,8 +931,7 @@ void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int
 
 void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, hipStream_t s)
 {
-    int npix = w.W * w.H;
-    hipLaunchKernelGGL(wf_accumulate_kernel, dim3((npix + kBlock - 1) / kBlock), dim3(kBlock), 0, s, w, cam, accum_dev);
+    hipLaunchKernelGGL(wf_accumulate_kernel, dim3((w.n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, w, cam, accum_dev);
 }
 
 } // namespace ptamd

@@ -476,8 +476,8 @@ def test_guided_environment_search_is_the_bisection():
 
 
 def test_one_and_two_lanes_agree_and_odd_frame_counts():
-    """Two concurrent lanes split every chunk of frames; one lane, two lanes, and frame counts that do not divide
-    evenly (or are smaller than the lane count) all give the oracle's accumulator."""
+    """Two concurrent lanes own alternate 64-pixel blocks of the image; one lane, two lanes, small pools and several
+    staging chunks all give the oracle's accumulator."""
     b = util.atrium(detail=0.3, env_size=(64, 32))
     P = scenes.atrium_params(ptamd.default_params(72, 40))
     want, st = orc.render(b.oracle(P), P, 2, 9, 12)
@@ -490,6 +490,18 @@ def test_one_and_two_lanes_agree_and_odd_frame_counts():
         r.render(P, 2, 9)
         _assert_radiance(r.read_accum(), want)
         assert r.counters()['rays'] == st['rays'] and r.counters()['samples'] == st['samples']
+        r.close()
+    # an image whose pixel count is not a multiple of the 64-pixel blocks the lanes deal out, and a one-block image
+    c = util.cornell('sky')
+    for W, H in ((37, 29), (7, 5)):
+        Pc = scenes.cornell_params(ptamd.default_params(W, H))
+        want, st = orc.render(c.oracle(Pc), Pc, 0, 5, 6)
+        r = c.renderer(Pc)
+        r.set_lanes(2)
+        r.set_pool(512, 2)
+        r.set_max_bounces(6)
+        r.render(Pc, 0, 5)
+        _assert_radiance(r.read_accum(), want)
         r.close()
 
 
