@@ -71,7 +71,7 @@ struct pt_ctx {
     int refill_lanes = 12, leaf_vote = 16, n_cus = 256;
     int extend_blocks_per_cu = 0;   // 0: 5 when one lane runs (all the LDS), 3 when two do
     // The wavefront loop runs as up to two independent lanes, each with its own slot pool, staging array,
-    // counters and stream, on disjoint frame ranges of a chunk: while one lane's traversal kernel (ALU bound)
+    // counters and stream, on disjoint pixels (alternate blocks of 64): while one lane's traversal kernel (ALU bound)
     // runs, the other lane's shading kernels (memory bound) can share the GPU.
     struct WfLane {
         hipStream_t stream = nullptr;   // lane 0 runs on the context's stream, the others on their own

@@ -2,21 +2,24 @@
 // kernels over a pool of path slots that live in HBM.
 //
 //   generate : every slot takes a sample id and builds its camera ray
+//   plan     : one workgroup lists the 256-slot blocks that hold rays (empty blocks then cost nothing)
 //   extend   : closest hit for the pending ray of every live slot (camera, bounce and shadow-walk
-//              rays alike); small register footprint, traversal stack in LDS, high occupancy
+//              rays alike): persistent waves over 4-wide quantized nodes, traversal stack in LDS
 //   shade    : consumes the hit (material resolve, medium/surface event, light-sample set-up, shadow
 //              segment bookkeeping); slots whose vertex is ready to pick its next direction are
-//              appended to the bsdf queue with a wave-aggregated atomic
+//              compacted into their workgroup's segment of the bsdf queue
 //   bsdf     : Disney evaluation for the light sample, direction sampling, roulette (the fat,
 //              divergent code), run only over the compacted queue
+//   drain    : once every sample has been started and few paths remain, each runs to its end in one
+//              kernel instead of one launch sequence per remaining path vertex
 //   accumulate: adds the per-sample results to the accumulator in frame order per pixel
 //
 // A slot whose sample is finished writes the sample's value to a staging array and immediately
-// takes the next unstarted sample id from a global counter (wave-aggregated), so the pool stays
+// takes the next unstarted sample id (from a 256-id chunk its workgroup holds), so the pool stays
 // full until the work runs out.  Which slot renders which sample does not matter: a sample's value
 // depends only on (pixel, frame) through its counter-based random stream, and the ordered
 // accumulate pass makes the sum independent of scheduling.  Results are therefore bit-identical to
-// the frame loop of the reference (pathtracer.cu:583-586) whatever the pool size.
+// the frame loop of the reference (pathtracer.cu:583-586) whatever the pool size or lane count.
 #include <hip/hip_runtime.h>
 #include "pt_path.hpp"
 #include "pt_launch.h"
