@@ -86,13 +86,17 @@ struct pt_ctx {
         WfParams w{};
         int batch = 8;
         bool finished = true;
+        size_t pool_slots = 0;          // slots each of the block's two pools has room for
+        int pool_side = 0;              // which of the two pools w points into
+        bool all_started = false;       // the host has seen every sample id handed out to some workgroup
     };
     static constexpr int kMaxLanes = 2;
     WfLane lanes[kMaxLanes];
     int n_lanes = 2;
     bool lanes_forced = false;      // pt_set_lanes was called: use that count whatever the render size
     hipEvent_t ev_fork = nullptr;
-    uint64_t wf_iterations = 0;
+    uint64_t wf_iterations = 0, wf_repacks = 0;
+    int repack_percent = 50;        // repack the pool when the live slots are at most this share of it (0: never)
     bool stage_timing = false;
     double extend_ms = 0.0;
     uint64_t extend_launches = 0;
@@ -697,19 +701,18 @@ static int lane_counters(pt_ctx::WfLane& L)
     return PT_OK;
 }
 
-// Lays the slot arrays of a lane out in its block (grown if needed) for `slots` slots.
-static int lane_pool(pt_ctx* c, pt_ctx::WfLane& L, size_t slots, WfParams* w)
+// Bytes of one slot pool of `slots` slots (a multiple of 256): 13 arrays of 16 bytes per slot, the bsdf queue,
+// and the per-block words (queue counts, sample chunks, ray counts, ray block list).
+static size_t pool_bytes(size_t slots)
 {
-    size_t per_slot = 13 * sizeof(float4) + sizeof(uint32_t);
-    size_t need = slots * per_slot + (slots / 256) * sizeof(uint32_t) + (slots / 64) * 2 * sizeof(uint32_t);
-    if (need > L.block_bytes) {
-        if (L.block) { (void)hipFree(L.block); L.block = nullptr; L.block_bytes = 0; }
-        HIP_TRY(hipMalloc(&L.block, need));
-        L.block_bytes = need;
-    }
-    int rc = lane_counters(L);
-    if (rc != PT_OK) return rc;
-    float4* base = (float4*)L.block;
+    size_t b = slots * (13 * sizeof(float4) + sizeof(uint32_t)) + (slots / 256) * 5 * sizeof(uint32_t);
+    return (b + 255) / 256 * 256;
+}
+
+// Points w's slot arrays into the pool that starts at `base`.
+static void pool_layout(pt_ctx* c, pt_ctx::WfLane& L, void* base_ptr, size_t slots, WfParams* w)
+{
+    float4* base = (float4*)base_ptr;
     float4** arrays[13] = {&w->ray_o, &w->ray_d, &w->hit, &w->c0, &w->c1, &w->c2, &w->d0, &w->d1, &w->e0, &w->e1, &w->e2, &w->e3, &w->e4};
     for (int i = 0; i < 13; i++) *arrays[i] = base + (size_t)i * slots;
     w->bsdf_queue = (uint32_t*)(base + (size_t)13 * slots);
@@ -719,8 +722,43 @@ static int lane_pool(pt_ctx* c, pt_ctx::WfLane& L, size_t slots, WfParams* w)
     w->chunk_list = w->chunk_rays + slots / 256;
     w->counters = L.counters;
     w->n_slots = (int)slots;
+}
+
+// Lays the slot arrays of a lane out in its block (grown if needed) for `slots` slots. The block holds two
+// pools of that size: the second one receives the live slots when the pool is repacked (and the first one
+// when it is repacked again).
+static int lane_pool(pt_ctx* c, pt_ctx::WfLane& L, size_t slots, WfParams* w)
+{
+    size_t need = 2 * pool_bytes(slots);
+    if (need > L.block_bytes) {
+        if (L.block) { (void)hipFree(L.block); L.block = nullptr; L.block_bytes = 0; }
+        HIP_TRY(hipMalloc(&L.block, need));
+        L.block_bytes = need;
+    }
+    int rc = lane_counters(L);
+    if (rc != PT_OK) return rc;
+    L.pool_slots = slots;
+    L.pool_side = 0;
+    pool_layout(c, L, L.block, slots, w);
     w->refill_lanes = c->refill_lanes; w->leaf_vote = c->leaf_vote;
     w->extend_blocks = (c->extend_blocks_per_cu ? c->extend_blocks_per_cu : 5) * c->n_cus;
+    return PT_OK;
+}
+
+// Moves the lane's live slots to the front of its other pool, sized for `live_bound` slots (an upper bound
+// of the live count), and makes that pool the current one.
+static int lane_repack(pt_ctx* c, pt_ctx::WfLane& L, uint32_t live_bound)
+{
+    size_t slots = ((size_t)live_bound + 255) / 256 * 256;
+    if (slots < 256) slots = 256;
+    WfParams dst = L.w;
+    int side = 1 - L.pool_side;
+    pool_layout(c, L, (char*)L.block + (size_t)side * pool_bytes(L.pool_slots), slots, &dst);
+    launch_wf_repack(L.w, dst, L.stream);
+    HIP_TRY(hipGetLastError());
+    L.w = dst;
+    L.pool_side = side;
+    c->wf_repacks++;
     return PT_OK;
 }
 
@@ -806,6 +844,7 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
             HIP_TRY(hipGetLastError());
             L.batch = (size_t)L.w.n_slots >= (size_t)L.w.n_samples ? 2 : kMaxBatch;
             L.finished = false;
+            L.all_started = false;
             rc = lane_issue_batch(c, L, cam, ctr);
             if (rc != PT_OK) return rc;
         }
@@ -818,7 +857,11 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
                     for (int k = 0; k < L.batch; k++) { float ms = 0.f; if (hipEventElapsedTime(&ms, L.st_ev[2 * k], L.st_ev[2 * k + 1]) == hipSuccess) { c->extend_ms += ms; c->extend_launches++; } }
                 }
                 const uint32_t* hc = L.host_counters;
-                if (hc[WF_CTR_NEXT_SAMPLE] >= L.w.n_samples) L.batch = 2;
+                // The counters of the planning pass (rays, leftover ids) are older than the last iteration of the
+                // batch: they bound what is in the pool now only if no workgroup could take new ids meanwhile,
+                // that is if the global cursor had run out before the batch was issued.
+                const bool settled = L.all_started;
+                if (hc[WF_CTR_NEXT_SAMPLE] >= L.w.n_samples) { L.batch = 2; L.all_started = true; }
                 bool done = hc[WF_CTR_LIVE] == 0;
                 // all sample ids handed out and few paths left: finish them in one kernel instead of one stage
                 // launch sequence per remaining path vertex
@@ -826,6 +869,12 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
                     launch_wf_drain(L.w, c->scene, cam, (int)hc[WF_CTR_RAYS], ctr, L.stream);
                     HIP_TRY(hipGetLastError());
                     done = true;
+                }
+                // all sample ids started and the pool mostly empty: move the live slots together
+                if (!done && c->repack_percent > 0 && settled && hc[WF_CTR_LEFTOVER] == 0 &&
+                    (uint64_t)hc[WF_CTR_RAYS] * 100u <= (uint64_t)L.w.n_slots * (uint64_t)c->repack_percent && L.w.n_slots > 256) {
+                    int rc = lane_repack(c, L, hc[WF_CTR_RAYS]);
+                    if (rc != PT_OK) return rc;
                 }
                 if (done) {
                     launch_wf_accumulate(L.w, cam, c->accum, L.stream);
@@ -869,6 +918,21 @@ int pt_debug_words(pt_ctx* c, unsigned long long* out16)
         HIP_TRY(hipMemset(c->lanes[i].counters + WF_CTR_WORDS, 0, sizeof(part)));
         for (int k = 0; k < 16; k++) out16[k] += part[k];
     }
+    return PT_OK;
+}
+
+int pt_set_repack(pt_ctx* c, int percent)
+{
+    if (!c || percent < 0 || percent > 100) { set_error("pt_set_repack: bad argument"); return PT_ERR_ARG; }
+    c->repack_percent = percent;
+    return PT_OK;
+}
+
+int pt_wavefront_stats(pt_ctx* c, uint64_t* iterations_out, uint64_t* repacks_out)
+{
+    if (!c) { set_error("null context"); return PT_ERR_ARG; }
+    if (iterations_out) *iterations_out = c->wf_iterations;
+    if (repacks_out) *repacks_out = c->wf_repacks;
     return PT_OK;
 }
 

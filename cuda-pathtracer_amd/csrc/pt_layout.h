@@ -112,6 +112,7 @@ enum : int {
     WF_CTR_RAY_NEXT = 4,      // next entry of chunk_list the extend kernel hands to a wave
     WF_CTR_RAY_CHUNKS = 5,    // entries in chunk_list
     WF_CTR_RAYS = 6,          // rays waiting at the last planning pass
+    WF_CTR_LEFTOVER = 7,      // sample ids workgroups still hold in their chunks at the last planning pass
     WF_CTR_WORDS = 8
 };
 struct WfParams {

@@ -816,12 +816,14 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate_kernel(WfParams w, DCame
 // Runs before every extend launch (one workgroup): compacts the indices of the slot blocks that hold rays
 // into chunk_list, publishes their number, and resets the per-iteration counters.
 __global__ __launch_bounds__(kPlanThreads) void wf_plan_extend_kernel(uint32_t* __restrict__ counters, const uint32_t* __restrict__ chunk_rays,
-                                                                      uint32_t* __restrict__ chunk_list, int n_chunks)
+                                                                      uint32_t* __restrict__ chunk_list, int n_chunks,
+                                                                      const uint32_t* __restrict__ block_chunk, uint32_t n_samples)
 {
     __shared__ uint32_t s_wave[kPlanThreads / 64];
     __shared__ uint32_t s_rays[kPlanThreads / 64];
+    __shared__ uint32_t s_left[kPlanThreads / 64];
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    uint32_t base = 0, rays = 0;
+    uint32_t base = 0, rays = 0, leftover = 0;
     for (int tile = 0; tile < n_chunks; tile += kPlanThreads * 4) {
         int i0 = tile + tid * 4;
         uint32_t r[4];
@@ -829,20 +831,30 @@ __global__ __launch_bounds__(kPlanThreads) void wf_plan_extend_kernel(uint32_t* 
         for (int k = 0; k < 4; k++) r[k] = (i0 + k < n_chunks) ? chunk_rays[i0 + k] : 0u;
         uint32_t mine = (r[0] != 0) + (r[1] != 0) + (r[2] != 0) + (r[3] != 0);
         uint32_t rsum = r[0] + r[1] + r[2] + r[3];
+        uint32_t lsum = 0;          // sample ids still waiting in these blocks' chunks
+        if (block_chunk) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (i0 + k < n_chunks) {
+                uint32_t cur = block_chunk[2 * (i0 + k)], end = block_chunk[2 * (i0 + k) + 1];
+                cur = cur < n_samples ? cur : n_samples; end = end < n_samples ? end : n_samples;
+                lsum += end > cur ? end - cur : 0u;
+            }
+        }
         uint32_t incl = mine;
 #pragma unroll
         for (int dlt = 1; dlt < 64; dlt <<= 1) {
             uint32_t t = (uint32_t)__shfl_up((int)incl, dlt, 64);
             uint32_t tr = (uint32_t)__shfl_xor((int)rsum, dlt, 64);
+            uint32_t tl = (uint32_t)__shfl_xor((int)lsum, dlt, 64);
             if (lane >= dlt) incl += t;
-            rsum += tr;
+            rsum += tr; lsum += tl;
         }
         if (lane == 63) s_wave[wid] = incl;
-        if (lane == 0) s_rays[wid] = rsum;
+        if (lane == 0) { s_rays[wid] = rsum; s_left[wid] = lsum; }
         __syncthreads();
         uint32_t woff = 0, total = 0;
 #pragma unroll
-        for (int j = 0; j < kPlanThreads / 64; j++) { uint32_t c = s_wave[j]; if (j < wid) woff += c; total += c; rays += s_rays[j]; }
+        for (int j = 0; j < kPlanThreads / 64; j++) { uint32_t c = s_wave[j]; if (j < wid) woff += c; total += c; rays += s_rays[j]; leftover += s_left[j]; }
         uint32_t pos = base + woff + incl - mine;
 #pragma unroll
         for (int k = 0; k < 4; k++) if (r[k] != 0) chunk_list[pos++] = (uint32_t)(i0 + k);
@@ -854,6 +866,7 @@ __global__ __launch_bounds__(kPlanThreads) void wf_plan_extend_kernel(uint32_t* 
         counters[WF_CTR_RAY_NEXT] = 0;
         counters[WF_CTR_RAY_CHUNKS] = base;
         counters[WF_CTR_RAYS] = rays;
+        counters[WF_CTR_LEFTOVER] = leftover;
     }
 }
 
@@ -880,7 +893,7 @@ void launch_wf_trace(const WfParams& w, const DScene& S, const pt_ray* rays_dev,
 {
     dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
     hipLaunchKernelGGL(wf_pack_rays_kernel, grid, block, 0, s, rays_dev, n, w.ray_o, w.ray_d, w.chunk_rays);
-    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, (int)grid.x);
+    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, (int)grid.x, (const uint32_t*)nullptr, 0u);
     int ext_blocks = (int)grid.x < w.extend_blocks ? (int)grid.x : w.extend_blocks;
     if (S.wide) hipLaunchKernelGGL((wf_extend_kernel<false, true>), dim3(ext_blocks), block, 0, s, w, S, (DCounters*)nullptr);
     else hipLaunchKernelGGL((wf_extend_kernel<false, false>), dim3(ext_blocks), block, 0, s, w, S, (DCounters*)nullptr);
@@ -898,7 +911,7 @@ void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, h
 void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t ext0, hipEvent_t ext1)
 {
     dim3 grid((w.n_slots + kBlock - 1) / kBlock), block(kBlock);
-    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, w.n_slots / kBlock);
+    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, w.n_slots / kBlock, (const uint32_t*)w.block_chunk, w.n_samples);
     if (ext0) (void)hipEventRecord(ext0, s);
     // persistent waves: enough workgroups to fill every CU, each pulls rays until the pool is drained
     int ext_blocks = (w.n_slots + kBlock - 1) / kBlock;
@@ -916,13 +929,52 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
     }
 }
 
+// ---------------------------------------------------------------- repack
+// While a render runs down, the slots that still carry a path are scattered over the pool and every stage
+// pays for the dead ones around them. Once no workgroup holds sample ids any more, the live slots can be
+// moved, in order, to the front of a second, smaller pool; the stages then run on dense blocks again.
+__global__ __launch_bounds__(kBlock) void wf_repack_kernel(WfParams src, WfParams dst, const uint32_t* __restrict__ live_list)
+{
+    const uint32_t n_live = src.counters[WF_CTR_RAYS];
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;       // destination slot; the grid covers dst.n_slots
+    if (i < n_live) {
+        const uint32_t s = live_list[i];
+        dst.ray_o[i] = src.ray_o[s]; dst.ray_d[i] = src.ray_d[s];
+        dst.c0[i] = src.c0[s]; dst.c1[i] = src.c1[s]; dst.c2[i] = src.c2[s];
+        dst.d0[i] = src.d0[s]; dst.d1[i] = src.d1[s];
+        dst.e0[i] = src.e0[s]; dst.e1[i] = src.e1[s]; dst.e2[i] = src.e2[s]; dst.e3[i] = src.e3[s]; dst.e4[i] = src.e4[s];
+    } else {
+        // an empty slot: no ray, state "done", no sample
+        dst.ray_d[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
+        dst.c2[i] = make_float4(0.f, __uint_as_float((uint32_t)ST_DONE), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
+    }
+    if (threadIdx.x == 0) {
+        const uint32_t first = blockIdx.x * kBlock;
+        dst.chunk_rays[blockIdx.x] = n_live > first ? (n_live - first < (uint32_t)kBlock ? n_live - first : (uint32_t)kBlock) : 0u;
+        dst.block_chunk[2 * blockIdx.x] = src.n_samples;          // nothing left to hand out
+        dst.block_chunk[2 * blockIdx.x + 1] = src.n_samples;
+    }
+}
+
+// src: the lane's current pool; dst: arrays of a pool of dst.n_slots >= live slots (same counters and staging)
+void launch_wf_repack(const WfParams& src, const WfParams& dst, hipStream_t s)
+{
+    const int n_blocks = src.n_slots / kBlock;
+    uint32_t* chunk_base = src.bsdf_count;
+    uint32_t* live_list = src.bsdf_queue;
+    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, src.counters, src.chunk_rays, src.chunk_list, n_blocks, (const uint32_t*)src.block_chunk, src.n_samples);
+    hipLaunchKernelGGL(wf_drain_plan_kernel, dim3(1), dim3(kPlanThreads), 0, s, src.counters, src.chunk_rays, src.chunk_list, chunk_base);
+    hipLaunchKernelGGL(wf_drain_gather_kernel, dim3(n_blocks), dim3(kBlock), 0, s, src, chunk_base, live_list);
+    hipLaunchKernelGGL(wf_repack_kernel, dim3(dst.n_slots / kBlock), dim3(kBlock), 0, s, src, dst, live_list);
+}
+
 void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int max_paths, DCounters* ctr, hipStream_t s)
 {
     const int n_blocks = w.n_slots / kBlock;
     // the stage queues are idle now: their arrays hold the per-block bases and the dense list of slots
     uint32_t* chunk_base = w.bsdf_count;
     uint32_t* drain_list = w.bsdf_queue;
-    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, n_blocks);
+    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, n_blocks, (const uint32_t*)w.block_chunk, w.n_samples);
     hipLaunchKernelGGL(wf_drain_plan_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, chunk_base);
     hipLaunchKernelGGL(wf_drain_gather_kernel, dim3(n_blocks), dim3(kBlock), 0, s, w, chunk_base, drain_list);
     int max_blocks = (max_paths + kBlock - 1) / kBlock;

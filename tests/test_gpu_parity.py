@@ -505,6 +505,31 @@ def test_one_and_two_lanes_agree_and_odd_frame_counts():
         r.close()
 
 
+def test_repacked_pool_gives_the_same_image():
+    """Once every sample is started, the slots that still carry a path are moved together (into the lane's other
+    pool, and back at the next repack). With the drain kernel off the render runs down through many repacks; the
+    accumulator and every counter must be those of the oracle, on one lane and on two, with and without leftover
+    sample ids in the workgroups' chunks at the time the global cursor runs out."""
+    b = util.atrium(detail=0.3, env_size=(64, 32))
+    P = scenes.atrium_params(ptamd.default_params(72, 40))
+    want, st = orc.render(b.oracle(P), P, 0, 6, 24)
+    for lanes, pool, percent, drain in ((1, (1 << 20, 64), 90, 0), (2, (1 << 20, 64), 50, 0), (1, (2048, 64), 100, 0), (2, (4096, 2), 75, 64)):
+        r = b.renderer(P)
+        r.set_lanes(lanes)
+        r.set_pool(*pool)
+        r.set_drain(drain)
+        r.set_repack(percent)
+        r.set_max_bounces(24)
+        r.enable_counters(True)
+        r.render(P, 0, 6)
+        _assert_radiance(r.read_accum(), want)
+        ctr = r.counters()
+        for k in ('rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples'):
+            assert ctr[k] == st[k], (k, lanes, pool, percent)
+        assert r.wavefront_stats()['repacks'] >= 2, (lanes, pool, percent)
+        r.close()
+
+
 def test_gpu_built_tree_gives_the_same_image():
     """PT_BVH_GPU_LBVH: a Morton-order radix tree built on the device. Closest hits and therefore radiance do not
     depend on the tree; only traversal cost and the box/triangle test counters do."""
