@@ -434,6 +434,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         // ---- one interior step for every descending lane
         if (descending && WIDE) {
             // four children: entry distances on the quantized grid, culled against the best hit, then sorted
+            // (the same arithmetic as wide_step, written out here: the call, though inlined, measured 7 % slower)
             const uint32_t wd[12] = {__float_as_uint(n0.x), __float_as_uint(n0.y), __float_as_uint(n0.z), __float_as_uint(n0.w),
                                      __float_as_uint(n1.x), __float_as_uint(n1.y), __float_as_uint(n1.z), __float_as_uint(n1.w),
                                      __float_as_uint(n2.x), __float_as_uint(n2.y), __float_as_uint(n2.z), __float_as_uint(n2.w)};
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(kBlock) void wf_drain_gather_kernel(WfParams w, con
     if (live) drain_list[chunk_base[blockIdx.x] + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
 }
 
-template <bool COUNT>
+template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, DCamera cam, const uint32_t* __restrict__ drain_list, DCounters* ctr)
 {
     const uint32_t n_paths = w.counters[WF_CTR_RAYS];
@@ -760,7 +761,9 @@ __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, 
             bool shadow = P.state == ST_SHADOW;
             F3 ro = shadow ? P.so : P.o;
             F3 rd = shadow ? P.sd : P.d;
-            Hit h = closest_hit<kBlock, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
+            Hit h;
+            if (WIDE) h = closest_hit_wide<kBlock, kLdsDepth>(S, ro, rd, threadIdx.x);
+            else h = closest_hit<kBlock, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
             if (COUNT) tl.rays++;
             Surf info;
             resolve_hit<COUNT>(S, h, rd, info, tl.taps, tl.taps_r);
@@ -980,8 +983,9 @@ void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int
     int max_blocks = (max_paths + kBlock - 1) / kBlock;
     if (max_blocks > n_blocks) max_blocks = n_blocks;
     if (max_blocks < 1) max_blocks = 1;
-    if (ctr) hipLaunchKernelGGL(wf_drain_kernel<true>, dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
-    else hipLaunchKernelGGL(wf_drain_kernel<false>, dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
+    if (ctr) hipLaunchKernelGGL((wf_drain_kernel<true, false>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
+    else if (S.wide) hipLaunchKernelGGL((wf_drain_kernel<false, true>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
+    else hipLaunchKernelGGL((wf_drain_kernel<false, false>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
 }
 
 void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, hipStream_t s)
