@@ -311,6 +311,9 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
 //          tests, which then equal the oracle's counts.
 //   WIDE:  walks the 4-wide quantized nodes (closest hits do not depend on the visiting order).
 //   neither: the binary quantized nodes, for trees too deep for the 4-wide stack.
+#ifndef PT_TAIL_FACTOR
+#define PT_TAIL_FACTOR 2u
+#endif
 #ifndef PT_STAMPS
 #define PT_STAMPS 0      // diagnostic build: pass statistics of the extend kernel
 #endif
@@ -336,9 +339,10 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     bool more = true;
     uint32_t chunk_next = 0, chunk_end = 0;      // wave-uniform
     const uint32_t n_chunks = w.counters[WF_CTR_RAY_CHUNKS];
+    const uint32_t n_small = n_chunks < PT_TAIL_FACTOR * gridDim.x ? n_chunks : PT_TAIL_FACTOR * gridDim.x, n_big = n_chunks - n_small;
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
 #if PT_STAMPS
-    unsigned long long st_iters = 0, st_lanes = 0, st_leafphases = 0, st_refills = 0, st_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st_iters = 0, st_lanes = 0, st_leafphases = 0, st_refills = 0, st_leaflanes = 0, st_idle = 0, st_t0 = __builtin_amdgcn_s_memtime();
 #endif
 
     auto push = [&](int ref, float tn) {
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         const bool leaf_now = at_leaf && (__popcll(leaf_mask) >= w.leaf_vote || desc_mask == 0ull);
 #if PT_STAMPS
         st_iters++; st_lanes += __popcll(desc_mask); st_leafphases += __any(leaf_now) ? 1 : 0; st_refills += do_refill ? 1 : 0;
+        st_leaflanes += __popcll(__ballot(leaf_now)); st_idle += n_idle;
 #endif
         // ---- issue every load of the pass before anything waits: a pass then costs one memory latency,
         // not one per kind of work
@@ -393,11 +398,17 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                 uint32_t li = 0;
                 if (lane == 0) li = atomicAdd(w.counters + WF_CTR_RAY_NEXT, 1u);
                 li = (uint32_t)__builtin_amdgcn_readfirstlane((int)li);
-                if (li >= n_chunks) { more = false; chunk_end = chunk_next; }
-                else {
+                if (li >= n_big + 4u * n_small) { more = false; chunk_end = chunk_next; }
+                else if (li < n_big) {
                     uint32_t c = w.chunk_list[li] * (uint32_t)kRayChunk;
                     c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
                     chunk_next = c; chunk_end = c + kRayChunk;
+                } else {
+                    // the last blocks go out in quarters, so that no wave ends the launch alone with 256 rays
+                    uint32_t j = li - n_big;
+                    uint32_t c = w.chunk_list[n_big + (j >> 2)] * (uint32_t)kRayChunk + (j & 3u) * (uint32_t)(kRayChunk / 4);
+                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                    chunk_next = c; chunk_end = c + kRayChunk / 4;
                 }
             }
             const uint32_t avail = chunk_end - chunk_next;
@@ -554,10 +565,10 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         }
     }
 #if PT_STAMPS
-    if (lane == 0) {
+    if (lane == 0 && n_chunks * 10u >= (uint32_t)(w.n_slots / kRayChunk) * 9u) {      // full launches only
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(w.counters + WF_CTR_WORDS);
         atomicAdd(dbg + 0, __builtin_amdgcn_s_memtime() - st_t0); atomicAdd(dbg + 1, st_refills); atomicAdd(dbg + 3, st_iters);
-        atomicAdd(dbg + 4, st_lanes); atomicAdd(dbg + 5, st_leafphases); atomicAdd(dbg + 6, 1ull);
+        atomicAdd(dbg + 4, st_lanes); atomicAdd(dbg + 5, st_leafphases); atomicAdd(dbg + 6, 1ull); atomicAdd(dbg + 7, st_leaflanes); atomicAdd(dbg + 8, st_idle);
     }
 #endif
     flush_tally<COUNT>(ctr, tl, 0);

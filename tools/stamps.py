@@ -15,6 +15,7 @@ d = (C.c_ulonglong * 16)()
 lib.check(lib.lib().pt_debug_words(r.h, d))
 r.render(P, 4, 20)
 lib.check(lib.lib().pt_debug_words(r.h, d))
-total, refills, _, iters, lanes, leafph, waves = [d[i] for i in range(7)]
+total, refills, _, iters, lanes, leafph, waves, leaflanes, idle = [d[i] for i in range(9)]
 print('waves %d  iterations/wave %.0f  cycles/iteration %.0f  descending lanes/iteration %.1f  leaf passes/iteration %.3f  refills/iteration %.3f'
       % (waves, iters / waves, total / iters, lanes / iters, leafph / iters, refills / iters))
+print('lanes in a leaf pass %.1f  idle lanes/iteration %.1f  lanes waiting at a leaf/iteration %.1f' % (leaflanes / max(leafph, 1), idle / iters, 64 - lanes / iters - idle / iters))
