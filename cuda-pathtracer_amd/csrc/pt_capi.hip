@@ -1091,6 +1091,11 @@ int pt_load_texture_png(const char* path, int comps, float** texels_out, int* w,
     if (!path || !texels_out || !w || !h) { set_error("pt_load_texture_png: bad argument"); return PT_ERR_ARG; }
     return load_png_texture(path, comps, texels_out, w, h);
 }
+int pt_load_texture_image(const char* path, int comps, float** texels_out, int* w, int* h)
+{
+    if (!path || !texels_out || !w || !h) { set_error("pt_load_texture_image: bad argument"); return PT_ERR_ARG; }
+    return load_image_texture(path, comps, texels_out, w, h);
+}
 int pt_save_pfm(const char* path, const float* rgb, int w, int h) { return save_pfm(path, rgb, w, h); }
 int pt_load_pfm(const char* path, float** rgb_out, int* w, int* h)
 {

@@ -27,6 +27,8 @@ int load_hdr(const char* path, float** rgba_out, int* w, int* h);
 void build_env_cdf(const float* rgba, int w, int h, float* cdf_out, float* sum_out);
 int save_png(const char* path, const uint8_t* rgba, int w, int h);
 int load_png_texture(const char* path, int comps, float** texels_out, int* w, int* h);
+int load_image_texture(const char* path, int comps, float** texels_out, int* w, int* h);   // PNG or JPEG by signature
+int decode_jpeg(const uint8_t* data, size_t size, int* w, int* h, std::vector<uint8_t>& rgb);
 int save_pfm(const char* path, const float* rgb, int w, int h);
 int load_pfm(const char* path, float** rgb_out, int* w, int* h);
 void default_material(pt_material& m);

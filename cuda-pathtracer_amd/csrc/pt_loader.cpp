@@ -560,6 +560,41 @@ int load_png_texture(const char* path, int comps, float** texels_out, int* w_out
     return PT_OK;
 }
 
+// genTexture / genTexture_float for either format the reference's assets use: the file's signature decides.
+// A JPEG becomes the same array a PNG of the decoded pixels would (rows flipped, / 255, alpha 1).
+int load_image_texture(const char* path, int comps, float** texels_out, int* w_out, int* h_out)
+{
+    *texels_out = nullptr; *w_out = *h_out = 0;
+    if (comps != 1 && comps != 4) { set_error("load_image_texture: comps must be 1 or 4"); return PT_ERR_ARG; }
+    FILE* f = fopen(path, "rb");
+    if (!f) { set_error("cannot open %s", path); return PT_ERR_IO; }
+    uint8_t sig[2] = {0, 0};
+    size_t got = fread(sig, 1, 2, f);
+    if (got != 2 || !(sig[0] == 0xFF && sig[1] == 0xD8)) { fclose(f); return load_png_texture(path, comps, texels_out, w_out, h_out); }
+    std::vector<uint8_t> file(sig, sig + 2);
+    {
+        uint8_t buf[65536]; size_t n;
+        while ((n = fread(buf, 1, sizeof(buf), f)) > 0) file.insert(file.end(), buf, buf + n);
+        fclose(f);
+    }
+    int w = 0, h = 0;
+    std::vector<uint8_t> rgb;
+    int rc = decode_jpeg(file.data(), file.size(), &w, &h, rgb);
+    if (rc != PT_OK) return rc;
+    float* px = (float*)malloc((size_t)w * h * comps * sizeof(float));
+    if (!px) { set_error("out of memory"); return PT_ERR_NOMEM; }
+    for (int y = 0; y < h; y++) {
+        const uint8_t* src = &rgb[(size_t)y * w * 3];
+        float* dst = px + (size_t)(h - 1 - y) * w * comps;          // image_loader.h:15: rows flipped
+        for (int x = 0; x < w; x++) {
+            if (comps == 4) { dst[4 * x] = (float)src[3 * x] / 255.0f; dst[4 * x + 1] = (float)src[3 * x + 1] / 255.0f; dst[4 * x + 2] = (float)src[3 * x + 2] / 255.0f; dst[4 * x + 3] = 1.0f; }
+            else dst[x] = (float)src[3 * x] / 255.0f;
+        }
+    }
+    *texels_out = px; *w_out = w; *h_out = h;
+    return PT_OK;
+}
+
 // Portable float map, little endian, three channels, rows bottom-up as the format prescribes: lossless
 // storage of the fp32 accumulator (checkpoint / resume of a progressive render, HDR output).
 int save_pfm(const char* path, const float* rgb, int w, int h)

@@ -138,7 +138,7 @@ int main(int argc, char** argv)
         const char* path = nullptr; int comps = 0;
         must(pt_host_scene_texture_info(hs, i, &path, &comps), "texture list");
         float* texels = nullptr; int tw = 0, th = 0;
-        must(pt_load_texture_png(path, comps, &texels, &tw, &th), "decoding a texture");
+        must(pt_load_texture_image(path, comps, &texels, &tw, &th), "decoding a texture");
         uint64_t handle = 0;
         must(pt_upload_texture(ctx, texels, tw, th, comps, &handle), "texture upload");
         pt_free(texels);

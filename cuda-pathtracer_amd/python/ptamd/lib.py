@@ -25,7 +25,7 @@ EXPORTS = [
     'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
     'pt_detmath_probe', 'pt_unorm8_probe', 'pt_set_texture_packing', 'pt_read_obj', 'pt_read_obj_general', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
     'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
-    'pt_host_build_bvh', 'pt_load_hdr', 'pt_load_texture_png', 'pt_build_env_cdf', 'pt_free', 'pt_camera_basis',
+    'pt_host_build_bvh', 'pt_load_hdr', 'pt_load_texture_png', 'pt_load_texture_image', 'pt_build_env_cdf', 'pt_free', 'pt_camera_basis',
 ]
 
 _lib = None
@@ -116,6 +116,16 @@ def load_hdr(path):
 def load_texture_png(path, comps):
     ptr, w, h = C.c_void_p(), C.c_int(), C.c_int()
     check(lib().pt_load_texture_png(path.encode(), C.c_int(comps), C.byref(ptr), C.byref(w), C.byref(h)))
+    try:
+        a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), (h.value, w.value, comps)).copy()
+    finally:
+        lib().pt_free(ptr)
+    return a
+
+
+def load_texture_image(path, comps):
+    ptr, w, h = C.c_void_p(), C.c_int(), C.c_int()
+    check(lib().pt_load_texture_image(path.encode(), C.c_int(comps), C.byref(ptr), C.byref(w), C.byref(h)))
     try:
         a = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), (h.value, w.value, comps)).copy()
     finally:

@@ -229,6 +229,7 @@ int pt_host_build_bvh(pt_triangle* tris, int* tri_idx, int n_tri, int flavour, p
 /* load_hdr_float4 (hdr_loader.h:253) + envMap::buildCDF (envmap.cpp:11-28). Caller frees with pt_free. */
 int pt_load_hdr(const char* path, float** rgba_out, int* w, int* h);
 int pt_load_texture_png(const char* path, int comps, float** texels_out, int* w, int* h); /* genTexture (comps 4) / genTexture_float (comps 1), image_loader.h:5-89, for PNG files: rows flipped, values / 255; free with pt_free, hand to pt_upload_texture */
+int pt_load_texture_image(const char* path, int comps, float** texels_out, int* w, int* h); /* the same for a PNG or a JPEG file (by signature): baseline and progressive Huffman JPEG, 1 or 3 components; sf::Image::loadFromFile, image_loader.h:8,52 */
 int pt_build_env_cdf(const float* rgba, int w, int h, float* cdf_out, float* sum_out);
 void pt_free(void* p);
 

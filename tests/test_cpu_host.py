@@ -330,6 +330,64 @@ def test_png_texture_decoder_matches_an_independent_decoder(tmp_path):
         assert np.array_equal(lib.load_texture_png(p, 4), scenes.decode_texture(p, 4)), p
 
 
+def test_jpeg_texture_decoder_agrees_with_libjpeg(tmp_path):
+    """pt_load_texture_image on JPEG files (the reference reads them through sf::Image, image_loader.h:8,52):
+    baseline and progressive, 4:4:4 / 4:2:2 / 4:2:0, grey, restart intervals, odd sizes. Decoders differ in the last
+    bits of the inverse transform and the chroma filter, so the bar is libjpeg's pixels within 3 levels, 0.1 on average;
+    the texture array is that image with rows flipped, / 255, alpha 1. Parity with the reference's own decoder is unpinned."""
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    y, x = np.mgrid[0:203, 0:317]
+    a = np.stack([127 + 100 * np.sin(x / 17.0 + y / 29.0), 127 + 100 * np.cos(x / 11.0 - y / 7.0), 127 + 90 * np.sin((x + y) / 23.0)], -1)
+    a = np.clip(a + rng.normal(0, 12, a.shape), 0, 255).astype(np.uint8)
+    d = str(tmp_path)
+    cases = [('444', a, dict(quality=90, subsampling=0)), ('422', a, dict(quality=90, subsampling=1)), ('420', a, dict(quality=50, subsampling=2)),
+             ('420p', a, dict(quality=90, subsampling=2, progressive=True)), ('444p', a, dict(quality=75, subsampling=0, progressive=True)),
+             ('grey', a[:, :, 0], dict(quality=85)), ('greyp', a[:, :, 0], dict(quality=85, progressive=True)),
+             ('1x1', a[:1, :1], dict(quality=90)), ('7x5', a[:5, :7], dict(quality=90, subsampling=2)), ('opt', a, dict(quality=90, subsampling=2, optimize=True)),
+             ('rst', a, dict(quality=90, subsampling=2, restart_marker_blocks=3))]
+    for name, img, kw in cases:
+        p = os.path.join(d, name + '.jpg')
+        Image.fromarray(img).save(p, 'JPEG', **kw)
+        ref = np.asarray(Image.open(p).convert('RGB')).astype(np.int32)
+        got = lib.load_texture_image(p, 4)
+        assert got.shape == ref.shape[:2] + (4,) and np.all(got[:, :, 3] == 1.0), name
+        px = got[::-1, :, :3] * np.float32(255)
+        assert np.array_equal(px, np.rint(px)), name                       # exact k / 255 values
+        diff = np.abs(px.astype(np.int32) - ref)
+        assert diff.max() <= 3 and diff.mean() < 0.1, (name, diff.max(), diff.mean())
+        assert np.array_equal(lib.load_texture_image(p, 1)[:, :, 0], got[:, :, 0]), name
+    # a PNG goes through the same entry point
+    Image.fromarray(a).save(os.path.join(d, 'a.png'))
+    assert np.array_equal(lib.load_texture_image(os.path.join(d, 'a.png'), 4), lib.load_texture_png(os.path.join(d, 'a.png'), 4))
+    # damaged and unsupported files are errors or images, never crashes
+    raw = open(os.path.join(d, '420p.jpg'), 'rb').read()
+    for cut in (2, 20, 200, len(raw) // 2, len(raw) - 2):
+        open(os.path.join(d, 'cut.jpg'), 'wb').write(raw[:cut])
+        try:
+            t = lib.load_texture_image(os.path.join(d, 'cut.jpg'), 4)
+            assert t.shape == (203, 317, 4)
+        except ptamd.PtError:
+            pass
+    noisy = bytearray(raw)
+    for k in rng.integers(600, len(raw) - 2, 40):
+        noisy[k] = int(rng.integers(0, 255))
+    open(os.path.join(d, 'noisy.jpg'), 'wb').write(bytes(noisy))
+    try:
+        lib.load_texture_image(os.path.join(d, 'noisy.jpg'), 4)
+    except ptamd.PtError:
+        pass
+    Image.fromarray(a).convert('CMYK').save(os.path.join(d, 'cmyk.jpg'), 'JPEG')
+    with pytest.raises(ptamd.PtError):
+        lib.load_texture_image(os.path.join(d, 'cmyk.jpg'), 4)
+    import glob
+    for p in sorted(glob.glob('/root/reference/Cuda Pathtracer/assets/models/**/*.jpg', recursive=True)):      # the JPEG textures the reference ships
+        ref = np.asarray(Image.open(p).convert('RGB')).astype(np.int32)
+        px = np.rint(lib.load_texture_image(p, 4)[::-1, :, :3] * 255).astype(np.int32)
+        diff = np.abs(px - ref)
+        assert diff.max() <= 3 and diff.mean() < 0.1, (p, diff.max(), diff.mean())
+
+
 def test_pfm_round_trip_is_lossless(tmp_path):
     rng = np.random.default_rng(6)
     img = rng.normal(0, 100, (7, 11, 3)).astype(np.float32)
