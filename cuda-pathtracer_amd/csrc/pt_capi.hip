@@ -1097,6 +1097,7 @@ int pt_load_texture_image(const char* path, int comps, float** texels_out, int* 
     return load_image_texture(path, comps, texels_out, w, h);
 }
 int pt_save_pfm(const char* path, const float* rgb, int w, int h) { return save_pfm(path, rgb, w, h); }
+int pt_save_exr(const char* path, const float* rgb, int w, int h, float scale) { return save_exr(path, rgb, w, h, scale); }
 int pt_load_pfm(const char* path, float** rgb_out, int* w, int* h)
 {
     if (!path || !rgb_out || !w || !h) { set_error("pt_load_pfm: bad argument"); return PT_ERR_ARG; }

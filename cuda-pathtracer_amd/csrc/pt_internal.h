@@ -30,6 +30,7 @@ int load_png_texture(const char* path, int comps, float** texels_out, int* w, in
 int load_image_texture(const char* path, int comps, float** texels_out, int* w, int* h);   // PNG or JPEG by signature
 int decode_jpeg(const uint8_t* data, size_t size, int* w, int* h, std::vector<uint8_t>& rgb);
 int save_pfm(const char* path, const float* rgb, int w, int h);
+int save_exr(const char* path, const float* rgb, int w, int h, float scale);
 int load_pfm(const char* path, float** rgb_out, int* w, int* h);
 void default_material(pt_material& m);
 

@@ -610,6 +610,48 @@ int save_pfm(const char* path, const float* rgb, int w, int h)
     return PT_OK;
 }
 
+// OpenEXR, the simplest conforming form: single part, scan lines in increasing y, no compression, three 32-bit
+// float channels (stored in the alphabetical order the format prescribes: B, G, R). Linear radiance for
+// compositing tools: the accumulator times `scale` (1 / frames).
+int save_exr(const char* path, const float* rgb, int w, int h, float scale)
+{
+    if (!path || !rgb || w <= 0 || h <= 0) { set_error("save_exr: bad argument"); return PT_ERR_ARG; }
+    std::vector<uint8_t> hd;
+    auto put = [&](const void* p, size_t n) { const uint8_t* b = (const uint8_t*)p; hd.insert(hd.end(), b, b + n); };
+    auto str = [&](const char* t) { put(t, strlen(t) + 1); };
+    auto i32 = [&](int32_t v) { put(&v, 4); };
+    auto f32 = [&](float v) { put(&v, 4); };
+    auto attr = [&](const char* name, const char* type, int32_t size) { str(name); str(type); i32(size); };
+    i32(20000630); i32(2);
+    attr("channels", "chlist", 3 * 18 + 1);
+    for (const char* ch : {"B", "G", "R"}) { str(ch); i32(2); uint8_t lin[4] = {0, 0, 0, 0}; put(lin, 4); i32(1); i32(1); }
+    hd.push_back(0);
+    attr("compression", "compression", 1); hd.push_back(0);
+    attr("dataWindow", "box2i", 16); i32(0); i32(0); i32(w - 1); i32(h - 1);
+    attr("displayWindow", "box2i", 16); i32(0); i32(0); i32(w - 1); i32(h - 1);
+    attr("lineOrder", "lineOrder", 1); hd.push_back(0);
+    attr("pixelAspectRatio", "float", 4); f32(1.f);
+    attr("screenWindowCenter", "v2f", 8); f32(0.f); f32(0.f);
+    attr("screenWindowWidth", "float", 4); f32(1.f);
+    hd.push_back(0);
+    FILE* f = fopen(path, "wb");
+    if (!f) { set_error("cannot write %s", path); return PT_ERR_IO; }
+    const uint64_t row_bytes = (uint64_t)w * 3 * sizeof(float), block = 8 + row_bytes;
+    bool ok = fwrite(hd.data(), 1, hd.size(), f) == hd.size();
+    const uint64_t first = hd.size() + (uint64_t)h * 8;
+    for (int y = 0; y < h && ok; y++) { uint64_t off = first + (uint64_t)y * block; ok = fwrite(&off, 8, 1, f) == 1; }
+    std::vector<float> line((size_t)w * 3);
+    for (int y = 0; y < h && ok; y++) {
+        const float* src = rgb + (size_t)y * w * 3;
+        for (int x = 0; x < w; x++) { line[x] = src[3 * x + 2] * scale; line[(size_t)w + x] = src[3 * x + 1] * scale; line[2 * (size_t)w + x] = src[3 * x] * scale; }
+        int32_t head[2] = {y, (int32_t)row_bytes};
+        ok = fwrite(head, 4, 2, f) == 2 && fwrite(line.data(), sizeof(float), line.size(), f) == line.size();
+    }
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) { set_error("short write to %s", path); return PT_ERR_IO; }
+    return PT_OK;
+}
+
 int load_pfm(const char* path, float** rgb_out, int* w_out, int* h_out)
 {
     *rgb_out = nullptr; *w_out = *h_out = 0;

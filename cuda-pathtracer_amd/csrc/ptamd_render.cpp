@@ -43,6 +43,7 @@ void usage()
         "  --frames-per-call N   1 = call pt_render_frame per sample like the application; 0 = one headless call (default)\n"
         "  --post E,G,S      exposure, gamma, saturation of the window's post-process (default: off)\n"
         "  --out FILE.png    displayed image (default out.png)    --pfm FILE.pfm   fp32 accumulator\n"
+        "  --exr FILE.exr    linear radiance (accumulator / frames), 32-bit float OpenEXR\n"
         "  --resume FILE.pfm --resume-frames K   continue from a saved accumulator of K frames\n"
         "  --gpu ID          device (default 0)\n");
     std::exit(2);
@@ -64,7 +65,7 @@ bool parse_floats(const char* s, float* out, int n)
 
 int main(int argc, char** argv)
 {
-    std::string obj, dir, subdir, hdr, out = "out.png", pfm, resume;
+    std::string obj, dir, subdir, hdr, out = "out.png", pfm, exr, resume;
     int W = 1920, H = 1080, spp = 64, bounces = 512, gpu = 0, per_call = 0, resume_frames = 0;
     float origin[3] = {0.f, 1.5f, 5.f}, angle[2] = {0.f, 0.f}, fov = 1.f, dof = 0.f, focal = 200.f, post[3] = {1.f, 1.f, 1.f};
     bool preview = false, sunsky = false, use_post = false, general = false;
@@ -78,6 +79,7 @@ int main(int argc, char** argv)
         else if (a == "--hdr") hdr = val();
         else if (a == "--out") out = val();
         else if (a == "--pfm") pfm = val();
+        else if (a == "--exr") exr = val();
         else if (a == "--resume") resume = val();
         else if (a == "--resume-frames") resume_frames = std::atoi(val());
         else if (a == "--size") { if (std::sscanf(val(), "%dx%d", &W, &H) != 2) usage(); }
@@ -192,10 +194,11 @@ int main(int argc, char** argv)
     }
     std::printf("rendered %d frames of %dx%d in %.3f s (%.2f Msamples/s)\n", spp, W, H, t_render, (double)W * H * spp / t_render / 1e6);
     must(pt_save_png(out.c_str(), rgba.data(), W, H), "writing the image");
-    if (!pfm.empty()) {
+    if (!pfm.empty() || !exr.empty()) {
         std::vector<float> acc((size_t)W * H * 3);
         must(pt_read_accum(ctx, acc.data()), "reading the accumulator");
-        must(pt_save_pfm(pfm.c_str(), acc.data(), W, H), "writing the accumulator");
+        if (!pfm.empty()) must(pt_save_pfm(pfm.c_str(), acc.data(), W, H), "writing the accumulator");
+        if (!exr.empty()) must(pt_save_exr(exr.c_str(), acc.data(), W, H, 1.0f / (float)total), "writing the radiance image");
     }
     pt_destroy(ctx);
     return 0;

@@ -21,7 +21,7 @@ EXPORTS = [
     'pt_last_error', 'pt_create', 'pt_destroy', 'pt_set_stream', 'pt_init', 'pt_clear_accum', 'pt_upload_triangles',
     'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_upload_texture', 'pt_upload_envmap',
     'pt_set_sky_mode', 'pt_set_env_guides', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_set_repack', 'pt_wavefront_stats', 'pt_set_lanes', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
-    'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
+    'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_save_exr', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
     'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
     'pt_detmath_probe', 'pt_unorm8_probe', 'pt_set_texture_packing', 'pt_read_obj', 'pt_read_obj_general', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
     'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
@@ -159,6 +159,12 @@ def save_pfm(path, rgb):
     rgb = np.ascontiguousarray(rgb, dtype=np.float32)
     h, w, _ = rgb.shape
     check(lib().pt_save_pfm(path.encode(), _p(rgb), C.c_int(w), C.c_int(h)))
+
+
+def save_exr(path, rgb, scale=1.0):
+    rgb = np.ascontiguousarray(rgb, dtype=np.float32)
+    h, w, _ = rgb.shape
+    check(lib().pt_save_exr(path.encode(), _p(rgb), C.c_int(w), C.c_int(h), C.c_float(scale)))
 
 
 def load_pfm(path):

@@ -192,6 +192,7 @@ int pt_resolve_display(pt_ctx* ctx, int n_frames, uint8_t* rgba_out);   /* accum
 int pt_save_png(const char* path, const uint8_t* rgba, int w, int h);   /* saveToFile, main.cpp:96-114 */
 int pt_resolve_display_post(pt_ctx* ctx, int n_frames, const pt_params* params, uint8_t* rgba_out); /* pt_resolve_display + the window's post-process shader, post_process.glsl:19-23 (exposure, mult, saturation, gamma of params) */
 int pt_save_pfm(const char* path, const float* rgb, int w, int h);       /* fp32 accumulator to a portable float map: checkpoint of a progressive render (the reference has none; it saves PNG only, main.cpp:96-114) */
+int pt_save_exr(const char* path, const float* rgb, int w, int h, float scale); /* rgb * scale (1 / frames: linear radiance) as an uncompressed 32-bit float scan-line OpenEXR file; the reference only saves the tone-mapped PNG (main.cpp:96-114) */
 int pt_load_pfm(const char* path, float** rgb_out, int* w, int* h);      /* read it back (free with pt_free); feed pt_write_accum to resume */
 
 /* ---- closest-hit batch (test and measurement entry) ---- */

@@ -407,6 +407,42 @@ def test_pfm_round_trip_is_lossless(tmp_path):
 
 
 # ------------------------------------------------------------------ BVH builder
+def test_exr_writer_is_readable_by_the_format_rules(tmp_path):
+    """pt_save_exr: single-part scan-line OpenEXR, no compression, float B/G/R channels; parsed back here by the
+    published layout (magic, version, attribute list, line offset table, one block per scan line)."""
+    rng = np.random.default_rng(9)
+    img = rng.normal(0, 50, (5, 7, 3)).astype(np.float32)
+    p = str(tmp_path / 'a.exr')
+    lib.save_exr(p, img, 0.25)
+    raw = open(p, 'rb').read()
+    assert struct.unpack_from('<ii', raw, 0) == (20000630, 2)
+    pos, attrs = 8, {}
+    while raw[pos] != 0:
+        e = raw.index(b'\0', pos); name = raw[pos:e].decode(); pos = e + 1
+        e = raw.index(b'\0', pos); typ = raw[pos:e].decode(); pos = e + 1
+        size, = struct.unpack_from('<i', raw, pos); pos += 4
+        attrs[name] = (typ, raw[pos:pos + size]); pos += size
+    pos += 1
+    assert attrs['compression'] == ('compression', b'\0') and attrs['lineOrder'] == ('lineOrder', b'\0')
+    assert struct.unpack('<4i', attrs['dataWindow'][1]) == (0, 0, 6, 4) == struct.unpack('<4i', attrs['displayWindow'][1])
+    ch, names, q = attrs['channels'][1], [], 0
+    while ch[q] != 0:
+        e = ch.index(b'\0', q); names.append(ch[q:e].decode()); q = e + 1
+        assert struct.unpack_from('<i4xii', ch, q) == (2, 1, 1); q += 16
+    assert names == ['B', 'G', 'R']
+    offsets = struct.unpack_from('<5Q', raw, pos)
+    out = np.zeros_like(img)
+    for y, off in enumerate(offsets):
+        yy, nbytes = struct.unpack_from('<ii', raw, off)
+        assert yy == y and nbytes == 7 * 3 * 4
+        row = np.frombuffer(raw, '<f4', 21, off + 8).reshape(3, 7)
+        out[y, :, 2], out[y, :, 1], out[y, :, 0] = row[0], row[1], row[2]
+    assert offsets[-1] + 8 + 84 == len(raw)
+    assert np.array_equal(out, img * np.float32(0.25))
+    with pytest.raises(ptamd.PtError):
+        lib.save_exr(str(tmp_path / 'no_such_dir' / 'a.exr'), img)
+
+
 @pytest.mark.parametrize('n,seed', [(1, 1), (2, 2), (3, 3), (37, 4), (500, 5), (3000, 6)])
 def test_host_builder_reproduces_the_reference_builder(n, seed):
     """The product's builder (binned sweeps, parallel subtrees) must emit the tree BVH_builder.cpp:12-128 builds
