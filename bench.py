@@ -53,6 +53,7 @@ def main():
     ap.add_argument('--device', type=int, default=-1, help='GPU to use (default: LOCAL_RANK)')
     ap.add_argument('--fp32-textures', action='store_true', help='keep 8-bit textures as fp32 texels instead of bytes')
     ap.add_argument('--repack', type=int, default=-1, help='repack threshold in percent of the pool (0 = never, -1 = library default)')
+    ap.add_argument('--env-guides', type=int, default=1, help='environment CDF search: 1 all guide tables, 2 without the whole-range table, 0 plain bisections')
     ap.add_argument('--lanes', type=int, default=0, help='concurrent wavefront lanes (0 = library default)')
     ap.add_argument('--drain', type=int, default=-1, help='finish the last paths in one kernel once at most this many remain (-1 = library default, 0 = never)')
     ap.add_argument('--node-width', type=int, default=4, help='4-wide or binary (2) compact nodes in the traversal kernel')
@@ -99,6 +100,8 @@ def main():
         r.set_lanes(args.lanes)
     if args.repack >= 0:
         r.set_repack(args.repack)
+    if args.env_guides != 1:
+        r.set_env_guides(args.env_guides)
     if args.tune:
         r.set_extend_tuning(*[int(x) for x in args.tune.split(',')])
     stream = torch.cuda.current_stream()

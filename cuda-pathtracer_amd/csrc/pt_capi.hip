@@ -56,7 +56,8 @@ struct pt_ctx {
     float* d_cdf = nullptr;
     float* d_env_tables = nullptr;   // row table [H] followed by column table [H*W]
     uint32_t* d_env_guides = nullptr; // row guide, column guides, one word of verification result
-    bool env_guides_ok = false, use_env_guides = true;
+    uint2* d_env_texel_guide = nullptr; // table over the whole range of xi, one word of verification result
+    bool env_guides_ok = false, use_env_guides = true, env_texel_guide_ok = false, use_env_texel_guide = true;
     DScene scene{};
     bool have_tris = false, have_bvh = false, have_mats = false, have_env = false;
     int max_bounces = 512;
@@ -157,6 +158,7 @@ void pt_destroy(pt_ctx* c)
     if (c->d_cdf) (void)hipFree(c->d_cdf);
     if (c->d_env_tables) (void)hipFree(c->d_env_tables);
     if (c->d_env_guides) (void)hipFree(c->d_env_guides);
+    if (c->d_env_texel_guide) (void)hipFree(c->d_env_texel_guide);
     if (c->own_accum) (void)hipFree(c->own_accum);
     if (c->display) (void)hipFree(c->display);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
@@ -575,8 +577,9 @@ int pt_upload_envmap(pt_ctx* c, const float* rgba, const float* cdf, int w, int 
     c->scene.env_rgba = c->d_env; c->scene.env_cdf = c->d_cdf;
     c->scene.env_w = w; c->scene.env_h = h; c->scene.env_sum = sum;
     // guide tables for the two CDF searches, trusted only if they reproduce the bisection at every breakpoint
-    c->scene.env_fast = 0;
-    c->env_guides_ok = false;
+    c->scene.env_fast = 0; c->scene.env_fast2 = 0;
+    c->env_guides_ok = false; c->env_texel_guide_ok = false;
+    if (c->d_env_texel_guide) { (void)hipFree(c->d_env_texel_guide); c->d_env_texel_guide = nullptr; }
     if (c->d_env_guides) { (void)hipFree(c->d_env_guides); c->d_env_guides = nullptr; }
     if (sum > 0.f && sum < 1e30f && w <= 65535 && h <= 65535) {
         size_t words = (size_t)kEnvRowBuckets + (size_t)h * kEnvColBuckets + 1;
@@ -594,6 +597,25 @@ int pt_upload_envmap(pt_ctx* c, const float* rgba, const float* cdf, int w, int 
         HIP_TRY(hipStreamSynchronize(c->stream));
         c->env_guides_ok = bad == 0;
         c->scene.env_fast = (c->env_guides_ok && c->use_env_guides) ? 1 : 0;
+        if (c->env_guides_ok) {
+            // the table over the whole range of xi, checked the same way with the guides above as its fallback
+            HIP_TRY(hipMalloc((void**)&c->d_env_texel_guide, (size_t)kEnvTexelBuckets * sizeof(uint2) + sizeof(uint32_t)));
+            uint32_t* d_bad2 = (uint32_t*)(c->d_env_texel_guide + kEnvTexelBuckets);
+            HIP_TRY(hipMemsetAsync(d_bad2, 0, sizeof(uint32_t), c->stream));
+            DScene probe = c->scene;
+            probe.env_fast = 1; probe.env_fast2 = 1;
+            probe.env_texel_guide = c->d_env_texel_guide;
+            probe.env_texel_scale = (float)kEnvTexelBuckets / sum;
+            launch_env_texel_guide(probe, c->d_env_texel_guide, d_bad2, c->stream);
+            HIP_TRY(hipGetLastError());
+            uint32_t bad2 = 1;
+            HIP_TRY(hipMemcpyAsync(&bad2, d_bad2, sizeof(bad2), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->env_texel_guide_ok = bad2 == 0;
+            c->scene.env_texel_guide = c->d_env_texel_guide;
+            c->scene.env_texel_scale = probe.env_texel_scale;
+            c->scene.env_fast2 = (c->env_texel_guide_ok && c->use_env_guides && c->use_env_texel_guide) ? 1 : 0;
+        }
     }
     c->have_env = true;
     if (params_io) {
@@ -607,8 +629,10 @@ int pt_set_env_guides(pt_ctx* c, int on, int* verified_out)
 {
     if (!c) { set_error("null context"); return PT_ERR_ARG; }
     c->use_env_guides = on != 0;
+    c->use_env_texel_guide = on != 2;        // 2: row and column guides only
     c->scene.env_fast = (c->env_guides_ok && c->use_env_guides) ? 1 : 0;
-    if (verified_out) *verified_out = c->env_guides_ok ? 1 : 0;
+    c->scene.env_fast2 = (c->env_texel_guide_ok && c->use_env_guides && c->use_env_texel_guide) ? 1 : 0;
+    if (verified_out) *verified_out = (c->env_guides_ok ? 1 : 0) | (c->env_texel_guide_ok ? 2 : 0);
     return PT_OK;
 }
 

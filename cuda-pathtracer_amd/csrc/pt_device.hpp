@@ -813,24 +813,41 @@ PT_DEV uint32_t env_bucket(float xi, float scale, int buckets)
     int k = f >= 0.f ? (int)f : 0;          // NaN and negatives go to bucket 0
     return (uint32_t)(k < buckets ? k : buckets - 1);
 }
+// Row and column sampleEnvMap's two searches end at (envmap_cuda.cu:28-57), clamped to the map as it does.
 template <bool COUNT>
-PT_DEV F2 env_search(const DScene& S, float xi, uint32_t& taps_r)
+PT_DEV void env_search_texel(const DScene& S, float xi, uint32_t& taps_r, int& x, int& y)
 {
     int row, col;
     if (!COUNT && S.env_fast) {
+        if (S.env_fast2) {
+            // one load names the row and the column range when xi's bucket lies inside a row (nearly always:
+            // there are about as many buckets as texels, and bright texels, where samples land, span several)
+            uint2 g = S.env_texel_guide[env_bucket(xi, S.env_texel_scale, kEnvTexelBuckets)];
+            if (g.x != 0xFFFFFFFFu) {
+                y = (int)g.x;
+                col = env_guided(S.env_col_table + (size_t)y * S.env_w, S.env_w, xi, g.y);
+                x = (int)clamp_((float)col, 0.f, (float)(S.env_w - 1));
+                return;
+            }
+        }
         row = env_guided(S.env_row_table, S.env_h, xi, S.env_row_guide[env_bucket(xi, S.env_row_scale, kEnvRowBuckets)]);
-        int y = (int)clamp_((float)row, 0.f, (float)(S.env_h - 1));
+        y = (int)clamp_((float)row, 0.f, (float)(S.env_h - 1));
         col = env_guided(S.env_col_table + (size_t)y * S.env_w, S.env_w, xi, S.env_col_guide[(size_t)y * kEnvColBuckets + env_bucket(xi, S.env_col_scale, kEnvColBuckets)]);
-        int x = (int)clamp_((float)col, 0.f, (float)(S.env_w - 1));
-        F2 uv = {(float)x / (float)S.env_w, (float)y / (float)S.env_h};
-        return uv;
+        x = (int)clamp_((float)col, 0.f, (float)(S.env_w - 1));
+        return;
     }
     // the value tex1(cdf, 1, mid/H) the reference looks up in the row search and tex1(cdf, mid/W, y/H) in the
     // column search, tabulated when the map was uploaded
     row = env_bisect<COUNT>(S.env_row_table, S.env_h, xi, taps_r);
-    int y = (int)clamp_((float)row, 0.f, (float)(S.env_h - 1));
+    y = (int)clamp_((float)row, 0.f, (float)(S.env_h - 1));
     col = env_bisect<COUNT>(S.env_col_table + (size_t)y * S.env_w, S.env_w, xi, taps_r);
-    int x = (int)clamp_((float)col, 0.f, (float)(S.env_w - 1));
+    x = (int)clamp_((float)col, 0.f, (float)(S.env_w - 1));
+}
+template <bool COUNT>
+PT_DEV F2 env_search(const DScene& S, float xi, uint32_t& taps_r)
+{
+    int x, y;
+    env_search_texel<COUNT>(S, xi, taps_r, x, y);
     F2 uv = {(float)x / (float)S.env_w, (float)y / (float)S.env_h};
     return uv;
 }

@@ -231,6 +231,62 @@ __global__ __launch_bounds__(256) void env_verify_kernel(DScene S, uint32_t* __r
     if (threadIdx.x == 0) { check(0.f); check(S.env_sum); check(S.env_sum * 2.f); }
     if (bad) atomicAdd(mismatches, bad);
 }
+// The table over the whole range of xi. Bucket k serves xi with k <= xi * scale < k + 1; the products and quotients
+// round (by up to 0.03 of a bucket at the top of the range), so each entry covers half a bucket more on either side.
+__global__ __launch_bounds__(256) void env_texel_guide_kernel(DScene S, uint2* __restrict__ guide)
+{
+    const int k = (int)(blockIdx.x * 256 + threadIdx.x);
+    if (k >= kEnvTexelBuckets) return;
+    uint32_t dummy = 0;
+    float lo_xi = ((float)k - 0.5f) / S.env_texel_scale, hi_xi = ((float)k + 1.5f) / S.env_texel_scale;
+    lo_xi = lo_xi > 0.f ? lo_xi : 0.f;
+    const bool last = k == kEnvTexelBuckets - 1;       // also takes every xi beyond the table
+    int row_lo = env_bisect<false>(S.env_row_table, S.env_h, lo_xi, dummy);
+    int row_hi = last ? S.env_h - 1 : env_bisect<false>(S.env_row_table, S.env_h, hi_xi, dummy);
+    uint2 g = make_uint2(0xFFFFFFFFu, 0u);
+    if (row_lo == row_hi && row_lo >= 2 && !last) {        // rows 0 and 1 involve the wrapped first entry: left to the general search
+        const float* table = S.env_col_table + (size_t)row_lo * S.env_w;
+        int lo = env_first_above(table, S.env_w, lo_xi), hi = env_first_above(table, S.env_w, hi_xi);
+        g = make_uint2((uint32_t)row_lo, (uint32_t)lo | ((uint32_t)hi << 16));
+    }
+    guide[k] = g;
+}
+// The complete search (texel guide, else row and column guides) against the two bisections, at every value where
+// either can change its answer: around each entry of both tables and around every bucket edge.
+__global__ __launch_bounds__(256) void env_verify_texel_kernel(DScene S, uint32_t* __restrict__ mismatches)
+{
+    const size_t n_col = (size_t)S.env_w * S.env_h, n_row = (size_t)S.env_h, n_edge = (size_t)kEnvTexelBuckets + 1;
+    uint32_t bad = 0, dummy = 0;
+    auto check = [&](float xi) {
+        if (!(xi >= 0.f)) return;
+        int row = env_bisect<false>(S.env_row_table, S.env_h, xi, dummy);
+        int y = (int)clamp_((float)row, 0.f, (float)(S.env_h - 1));
+        int col = env_bisect<false>(S.env_col_table + (size_t)y * S.env_w, S.env_w, xi, dummy);
+        int x = (int)clamp_((float)col, 0.f, (float)(S.env_w - 1));
+        int gx, gy;
+        env_search_texel<false>(S, xi, dummy, gx, gy);
+        if (gx != x || gy != y) bad++;
+    };
+    auto around = [&](float v, int reach) {
+        uint32_t b = __float_as_uint(v);
+        for (int d = -reach; d <= reach; d++) {
+            long long nb = (long long)b + d;
+            if (nb >= 0 && nb < 0x7f800000ll) check(__uint_as_float((uint32_t)nb));
+        }
+    };
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_col + n_row + n_edge; i += (size_t)gridDim.x * 256) {
+        if (i < n_col) around(S.env_col_table[i], 1);
+        else if (i < n_col + n_row) around(S.env_row_table[i - n_col], 1);
+        else around((float)(i - n_col - n_row) / S.env_texel_scale, 8);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+// S must have env_fast and env_fast2 set and env_texel_guide pointing at guide_dev
+void launch_env_texel_guide(const DScene& S, uint2* guide_dev, uint32_t* mismatches_dev, hipStream_t stream)
+{
+    hipLaunchKernelGGL(env_texel_guide_kernel, dim3(kEnvTexelBuckets / 256), dim3(256), 0, stream, S, guide_dev);
+    hipLaunchKernelGGL(env_verify_texel_kernel, dim3(2048), dim3(256), 0, stream, S, mismatches_dev);
+}
 void launch_env_guides(const DScene& S, uint32_t* row_guide_dev, uint32_t* col_guide_dev, uint32_t* mismatches_dev, hipStream_t stream)
 {
     hipLaunchKernelGGL(env_guides_kernel, dim3(1 + S.env_h), dim3(256), 0, stream, S.env_row_table, S.env_col_table, S.env_w, S.env_h,

@@ -16,6 +16,7 @@ void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_de
 void launch_wf_trace(const WfParams& w, const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, hipStream_t s);
 int gpu_build_lbvh(const pt_triangle* tris_dev, int n, pt_bvh_node* nodes_dev, int* tri_idx_dev, hipStream_t stream);
 void launch_env_tables(const float* cdf_dev, int w, int h, float* row_table_dev, float* col_table_dev, hipStream_t stream);
+void launch_env_texel_guide(const DScene& S, uint2* guide_dev, uint32_t* mismatches_dev, hipStream_t stream);
 void launch_env_guides(const DScene& S, uint32_t* row_guide_dev, uint32_t* col_guide_dev, uint32_t* mismatches_dev, hipStream_t stream);
 void launch_unorm8_probe(float* out_dev, hipStream_t stream);
 void launch_detmath_probe(const float* x_dev, const float* y_dev, int n, float* out_dev, hipStream_t stream);

@@ -79,6 +79,11 @@ struct DScene {
     const uint32_t* env_col_guide;   // [H][kEnvColBuckets]
     float env_row_scale, env_col_scale;
     int env_fast;
+    // One table over the whole range of xi: the bucket of xi gives the row and the column range directly
+    // when the bucket lies inside one row (x = row, y = first | last << 16), else x = 0xFFFFFFFF.
+    const uint2* env_texel_guide;    // [kEnvTexelBuckets]
+    float env_texel_scale;
+    int env_fast2;
     int env_w, env_h;
     float env_sum;
     int sky_mode;
@@ -90,6 +95,7 @@ struct DScene {
 
 constexpr int kEnvRowBuckets = 512;
 constexpr int kEnvColBuckets = 128;
+constexpr int kEnvTexelBuckets = 1 << 19;      // 4 MB: about one bucket per texel of a 1024x512 map
 
 struct DCamera {
     float origin[3], ww[3], uu[3], vv[3];

@@ -236,10 +236,11 @@ class Renderer:
         check(lib().pt_set_sky_mode(self.h, C.c_int(mode)))
 
     def set_env_guides(self, on):
-        """Returns True when the uploaded environment map passed the guide-table verification."""
+        """on: 0 plain bisections, 1 all guide tables, 2 without the whole-range table. Returns the verification
+        bits of the uploaded environment map: 1 row/column guides passed, 2 whole-range table passed."""
         ok = C.c_int()
-        check(lib().pt_set_env_guides(self.h, C.c_int(1 if on else 0), C.byref(ok)))
-        return bool(ok.value)
+        check(lib().pt_set_env_guides(self.h, C.c_int(int(on)), C.byref(ok)))
+        return ok.value
 
     def set_mode(self, mode):
         check(lib().pt_set_mode(self.h, C.c_int(mode)))

@@ -439,8 +439,10 @@ def test_degenerate_sizes_and_scenes(mode):
 
 
 def test_guided_environment_search_is_the_bisection():
-    """sampleEnvMap's two bisections start from guide tables when the upload-time check of every breakpoint passed;
-    renders with the guides on and off must agree bit for bit, on maps of very different shape."""
+    """sampleEnvMap's two bisections are answered from guide tables (one over the whole range of the random number,
+    row and column tables behind it) when the upload-time check of every breakpoint passed; renders with all
+    tables, without the whole-range table and with plain bisections must agree bit for bit, on maps of very
+    different shape."""
     b = util.cornell('sky')
     P = scenes.cornell_params(ptamd.default_params(64, 48))
     rng = np.random.default_rng(3)
@@ -452,7 +454,7 @@ def test_guided_environment_search_is_the_bisection():
     for env in maps:
         cdf, total = lib.build_env_cdf(env)
         out = []
-        for on in (True, False):
+        for on in (1, 2, 0):
             r = ptamd.Renderer(); r.init(P)
             r.upload_scene(b.tris, b.mats, b.idx, b.nodes)
             r.upload_envmap(env, cdf, total, P)
@@ -461,8 +463,8 @@ def test_guided_environment_search_is_the_bisection():
             r.render(P, 0, 3)
             out.append(r.read_accum())
             r.close()
-        assert verified, 'the guide tables of this map did not pass the check'
-        assert np.array_equal(bits(out[0]), bits(out[1]))
+        assert verified == 3, 'the guide tables of this map did not pass the check'
+        assert np.array_equal(bits(out[0]), bits(out[2])) and np.array_equal(bits(out[1]), bits(out[2]))
     S = b.oracle(P)
     S.env_rgba = np.ascontiguousarray(maps[1]); S.env_cdf, S.env_sum = lib.build_env_cdf(maps[1])
     want, _ = orc.render(S, P, 0, 3, 6)
