@@ -444,8 +444,12 @@ PT_DEV void default_mat(Mat& m)          // structs.cuh:75-94
 // pathtracer.cu:140-181: what triangleIntersect does after accepting a hit, evaluated once for the
 // final hit of a query (intermediate accepted hits never reach the caller).
 template <bool COUNT>
-PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& taps, uint32_t& taps_r)
+PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& taps, uint32_t& taps_r, bool visibility_only = false)
 {
+    // visibility_only: the caller is a segment of the visibility walk, which looks at alpha, metallic, specTrans, ior and
+    // the medium only (pathtracer.cu:279-295): the roughness, emission and normal maps are not fetched (the counting
+    // build fetches them, as the reference does, so its tap counts stay the reference's)
+    const bool all = COUNT || !visibility_only;
     s.t = h.t; s.hit = h.tri != PT_NO_TRI; s.inside = false; s.n = f3(0, 0, 0);
     default_mat(s.m);
     if (!s.hit) return;
@@ -481,10 +485,10 @@ PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& 
         s.m.alpha = r.w;
         if (COUNT) taps++;
     }
-    if (tx_r) { const DTex tx = S.tex[tx_r - 1]; s.m.rough = tex1_any(tx, px, py); if (COUNT) taps_r++; }
+    if (tx_r && all) { const DTex tx = S.tex[tx_r - 1]; s.m.rough = tex1_any(tx, px, py); if (COUNT) taps_r++; }
     if (tx_m) { const DTex tx = S.tex[tx_m - 1]; s.m.metal = tex1_any(tx, px, py); if (COUNT) taps_r++; }
-    if (tx_e) { const DTex tx = S.tex[tx_e - 1]; float r = tex1_any(tx, px, py); s.m.emis = f3(r, r, r); if (COUNT) taps_r++; }
-    if (tx_n) {
+    if (tx_e && all) { const DTex tx = S.tex[tx_e - 1]; float r = tex1_any(tx, px, py); s.m.emis = f3(r, r, r); if (COUNT) taps_r++; }
+    if (tx_n && all) {
         F3 Tn, Bn;
         onb(s.n, Tn, Bn);
         const DTex tx = S.tex[tx_n - 1];

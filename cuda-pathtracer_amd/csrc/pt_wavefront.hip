@@ -599,7 +599,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE
         Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
         F3 rdir = f3(rd4.x, rd4.y, rd4.z);
         Surf info;
-        resolve_hit<COUNT>(S, h, rdir, info, tl.taps, tl.taps_r);
+        resolve_hit<COUNT>(S, h, rdir, info, tl.taps, tl.taps_r, P.state == ST_SHADOW);
         if (P.state == ST_SHADOW) {
             P.so = f3(ro4.x, ro4.y, ro4.z); P.sd = rdir;
             on_shadow_hit<COUNT>(S, cam, P, info, tl);
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, 
             else h = closest_hit<kBlock, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
             if (COUNT) tl.rays++;
             Surf info;
-            resolve_hit<COUNT>(S, h, rd, info, tl.taps, tl.taps_r);
+            resolve_hit<COUNT>(S, h, rd, info, tl.taps, tl.taps_r, shadow);
             if (shadow) on_shadow_hit<COUNT>(S, cam, P, info, tl);
             else on_path_hit<COUNT>(S, cam, P, info, tl);
         }
