@@ -96,6 +96,18 @@ struct pt_ctx {
     int n_lanes = 2;
     bool lanes_forced = false;      // pt_set_lanes was called: use that count whatever the render size
     hipEvent_t ev_fork = nullptr;
+    // pt_render_frame renders a few frames ahead into the staging arrays while the caller keeps asking for the next
+    // frame of the same view; a staged frame is added to the accumulator when its call comes.
+    uint64_t epoch = 0;             // bumped by every call that changes what a sample evaluates to
+    int lookahead_max = 8;          // frames rendered per batch at most (1: no look-ahead)
+    struct Ahead {
+        bool valid = false;
+        uint64_t epoch = 0;
+        pt_params params{};         // the view the batch was rendered for
+        int first = 0, count = 0, next = 0, lanes = 0;
+        int streak = 0;             // consecutive calls that continued the previous one
+        int last_frame = -2;
+    } ahead;
     uint64_t wf_iterations = 0, wf_repacks = 0;
     int repack_percent = 50;        // repack the pool when the live slots are at most this share of it (0: never)
     bool stage_timing = false;
@@ -181,6 +193,7 @@ void pt_destroy(pt_ctx* c)
 
 int pt_set_stream(pt_ctx* c, void* s)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c) { set_error("null context"); return PT_ERR_ARG; }
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return PT_OK;
@@ -188,6 +201,7 @@ int pt_set_stream(pt_ctx* c, void* s)
 
 int pt_init(pt_ctx* c, const pt_params* p)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !p) { set_error("pt_init: null argument"); return PT_ERR_ARG; }
     int W = p->windowSize.x, H = p->windowSize.y;
     if (W <= 0 || H <= 0 || (int64_t)W * H > (1 << 28)) { set_error("pt_init: bad window size %dx%d", W, H); return PT_ERR_ARG; }
@@ -214,6 +228,7 @@ int pt_clear_accum(pt_ctx* c)
 
 int pt_upload_triangles(pt_ctx* c, const int* tri_idx, const pt_triangle* tris, int n)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !tris || n <= 0) { set_error("pt_upload_triangles: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     c->tris.assign(tris, tris + n);
@@ -245,6 +260,7 @@ static int tex_slot(const pt_ctx* c, uint64_t handle, uint8_t flag, int comps, c
 
 int pt_upload_materials(pt_ctx* c, const pt_material* mats, int n)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !mats || n <= 0) { set_error("pt_upload_materials: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     std::vector<DMat> dm(n);
@@ -288,6 +304,7 @@ int pt_upload_materials(pt_ctx* c, const pt_material* mats, int n)
 // lays triangles out in leaf order. Interior nodes are numbered in depth-first order.
 int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_used, int n_tri)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !nodes || nodes_used <= 0) { set_error("pt_upload_bvh: bad argument"); return PT_ERR_ARG; }
     if (!c->have_tris || n_tri != (int)c->tris.size()) { set_error("pt_upload_bvh: upload %d triangles first", n_tri); return PT_ERR_STATE; }
     if (root_idx < 0 || root_idx >= nodes_used) { set_error("pt_upload_bvh: bad root"); return PT_ERR_ARG; }
@@ -508,6 +525,7 @@ int pt_build_bvh(pt_ctx* c, int flavour)
 
 int pt_upload_texture(pt_ctx* c, const float* texels, int w, int h, int comps, uint64_t* handle_out)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !texels || !handle_out || w <= 0 || h <= 0 || (comps != 1 && comps != 4)) { set_error("pt_upload_texture: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     // 8-bit image data (every value exactly k/255) is kept as bytes: the sampler rebuilds the same floats
@@ -538,6 +556,7 @@ int pt_upload_texture(pt_ctx* c, const float* texels, int w, int h, int comps, u
 
 int pt_set_texture_packing(pt_ctx* c, int on)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c) { set_error("null context"); return PT_ERR_ARG; }
     c->pack_textures = on != 0;
     return PT_OK;
@@ -560,6 +579,7 @@ int pt_unorm8_probe(pt_ctx* c, float* out256)
 
 int pt_upload_envmap(pt_ctx* c, const float* rgba, const float* cdf, int w, int h, float sum, pt_params* params_io)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !rgba || !cdf || w <= 0 || h <= 0) { set_error("pt_upload_envmap: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     if (c->d_env) { (void)hipFree(c->d_env); c->d_env = nullptr; }
@@ -627,6 +647,7 @@ int pt_upload_envmap(pt_ctx* c, const float* rgba, const float* cdf, int w, int 
 
 int pt_set_env_guides(pt_ctx* c, int on, int* verified_out)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c) { set_error("null context"); return PT_ERR_ARG; }
     c->use_env_guides = on != 0;
     c->use_env_texel_guide = on != 2;        // 2: row and column guides only
@@ -638,6 +659,7 @@ int pt_set_env_guides(pt_ctx* c, int on, int* verified_out)
 
 int pt_set_sky_mode(pt_ctx* c, int mode)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || (mode != PT_SKY_ENVMAP && mode != PT_SKY_SUNSKY)) { set_error("pt_set_sky_mode: bad argument"); return PT_ERR_ARG; }
     c->scene.sky_mode = mode;
     return PT_OK;
@@ -645,6 +667,7 @@ int pt_set_sky_mode(pt_ctx* c, int mode)
 
 int pt_set_max_bounces(pt_ctx* c, int n)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || n < 0) { set_error("pt_set_max_bounces: bad argument"); return PT_ERR_ARG; }
     c->max_bounces = n;
     return PT_OK;
@@ -652,6 +675,7 @@ int pt_set_max_bounces(pt_ctx* c, int n)
 
 int pt_enable_counters(pt_ctx* c, int on)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c) { set_error("null context"); return PT_ERR_ARG; }
     c->counting = on != 0;
     return PT_OK;
@@ -836,8 +860,9 @@ static int lane_issue_batch(pt_ctx* c, pt_ctx::WfLane& L, const DCamera& cam, DC
 // Frames [f0, f1) through the stage kernels, in chunks that bound the staging memory. The lanes own disjoint
 // pixels (blocks of 64 dealt in turn) and each adds its staged samples to its pixels frame by frame, so every
 // pixel sees its additions in frame order whatever the lanes' timing was.
-static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
+static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1, bool hold = false, int* lanes_used = nullptr)
 {
+    c->ahead.valid = false;         // the staging arrays are about to be overwritten
     size_t npix = (size_t)c->W * c->H;
     int max_chunk = c->chunk_frames;
     while (max_chunk > 1 && npix * (size_t)max_chunk > ((size_t)1 << 30)) max_chunk /= 2;     // at most 2^30 samples (4 GiB of staging)
@@ -901,7 +926,7 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
                     if (rc != PT_OK) return rc;
                 }
                 if (done) {
-                    launch_wf_accumulate(L.w, cam, c->accum, L.stream);
+                    if (!hold) launch_wf_accumulate(L.w, cam, c->accum, 0, L.w.n_frames, L.stream);
                     HIP_TRY(hipGetLastError());
                     L.finished = true; remaining--;
                     continue;
@@ -910,6 +935,7 @@ static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1)
                 if (rc != PT_OK) return rc;
             }
         }
+        if (lanes_used) *lanes_used = n_lanes;
         // the context's stream continues after the other lanes
         for (int i = 1; i < n_lanes; i++) {
             HIP_TRY(hipEventRecord(c->lanes[i].ready, c->lanes[i].stream));
@@ -969,6 +995,7 @@ int pt_set_extend_tuning(pt_ctx* c, int refill_lanes, int leaf_vote, int blocks_
 
 int pt_set_node_width(pt_ctx* c, int width, int leaf_merge)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || (width != 2 && width != 4) || leaf_merge < 1 || leaf_merge > 16) { set_error("pt_set_node_width: width must be 2 or 4, leaf_merge 1..16"); return PT_ERR_ARG; }
     c->node_width = width;
     c->leaf_merge = leaf_merge;         // takes effect at the next pt_upload_bvh / pt_build_bvh
@@ -978,6 +1005,7 @@ int pt_set_node_width(pt_ctx* c, int width, int leaf_merge)
 
 int pt_set_mode(pt_ctx* c, int mode)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || (mode != PT_MODE_WAVEFRONT && mode != PT_MODE_SINGLE_KERNEL)) { set_error("pt_set_mode: bad argument"); return PT_ERR_ARG; }
     c->mode = mode;
     return PT_OK;
@@ -985,6 +1013,7 @@ int pt_set_mode(pt_ctx* c, int mode)
 
 int pt_set_lanes(pt_ctx* c, int lanes)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || lanes < 1 || lanes > pt_ctx::kMaxLanes) { set_error("pt_set_lanes: 1 or 2 lanes"); return PT_ERR_ARG; }
     c->n_lanes = lanes;
     c->lanes_forced = true;
@@ -1000,6 +1029,7 @@ int pt_set_drain(pt_ctx* c, int max_rays)
 
 int pt_set_pool(pt_ctx* c, int slots, int chunk_frames)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || slots < 64 || chunk_frames < 1) { set_error("pt_set_pool: bad argument"); return PT_ERR_ARG; }
     c->pool_slots = slots;
     c->chunk_frames = chunk_frames;
@@ -1036,6 +1066,24 @@ int pt_sync(pt_ctx* c)
     return PT_OK;
 }
 
+// Everything of params that a sample or the displayed image depends on, except the frame index and the
+// caller's buffer.
+static bool same_view(const pt_params& a, const pt_params& b)
+{
+    pt_params x = a, y = b;
+    x.frameIndex = y.frameIndex = 0;
+    x.pixelBuffer = y.pixelBuffer = nullptr;
+    return memcmp(&x, &y, sizeof(pt_params)) == 0;
+}
+
+int pt_set_frame_lookahead(pt_ctx* c, int max_frames)
+{
+    if (!c || max_frames < 1 || max_frames > 64) { set_error("pt_set_frame_lookahead: bad argument"); return PT_ERR_ARG; }
+    c->lookahead_max = max_frames;
+    c->ahead.valid = false;
+    return PT_OK;
+}
+
 int pt_render_frame(pt_ctx* c, pt_params* P)
 {
     int rc = check_ready(c, true);
@@ -1044,7 +1092,37 @@ int pt_render_frame(pt_ctx* c, pt_params* P)
     HIP_TRY(hipSetDevice(c->device));
     // pathtracer.cu:583-586: the first frame of a render and every preview frame overwrite
     if (P->frameIndex == 0 || !P->isRendering) { if ((rc = pt_clear_accum(c)) != PT_OK) return rc; }
-    if ((rc = pt_render_headless(c, P, P->frameIndex, P->frameIndex + 1)) != PT_OK) return rc;
+    pt_ctx::Ahead& A = c->ahead;
+    const bool can_stage = c->mode == PT_MODE_WAVEFRONT && P->isRendering && !c->counting && !c->stage_timing && c->lookahead_max > 1 &&
+                           P->frameIndex >= 0 && P->frameIndex < 524288 - 64;
+    // A caller that keeps asking for the next frame of one view (the reference's main loop while the camera rests,
+    // main.cpp:163-169) gets frames rendered ahead, 2, 4, ... lookahead_max at a time: a batch fills the GPU where a
+    // single 1-spp frame mostly ramps up and down. A staged frame joins the accumulator only when its call comes, in
+    // frame order, so every call returns exactly the image the one-frame-at-a-time loop would.
+    const bool continues = A.last_frame >= 0 && P->frameIndex == A.last_frame + 1 && A.epoch == c->epoch && same_view(*P, A.params);
+    A.streak = continues ? A.streak + 1 : 0;
+    bool staged = can_stage && A.valid && continues && P->frameIndex == A.next && A.next < A.first + A.count;
+    DCamera cam;
+    if (can_stage && !staged && A.streak >= 1) {
+        int k = 1 << (A.streak < 6 ? A.streak : 6);
+        k = k < c->lookahead_max ? k : c->lookahead_max;
+        if ((rc = make_camera(c, P, &cam)) != PT_OK) return rc;
+        HIP_TRY(hipEventRecord(c->ev0, c->stream));
+        int lanes = 0;
+        if ((rc = render_wavefront(c, cam, P->frameIndex, P->frameIndex + k, true, &lanes)) != PT_OK) return rc;
+        HIP_TRY(hipEventRecord(c->ev1, c->stream));
+        A.valid = true; A.first = A.next = P->frameIndex; A.count = k; A.lanes = lanes;
+        staged = true;
+    }
+    if (staged) {
+        if ((rc = make_camera(c, P, &cam)) != PT_OK) return rc;
+        for (int i = 0; i < A.lanes; i++) launch_wf_accumulate(c->lanes[i].w, cam, c->accum, A.next - A.first, 1, c->stream);
+        HIP_TRY(hipGetLastError());
+        A.next++;
+    } else {
+        if ((rc = pt_render_headless(c, P, P->frameIndex, P->frameIndex + 1)) != PT_OK) return rc;
+    }
+    A.params = *P; A.epoch = c->epoch; A.last_frame = P->isRendering ? P->frameIndex : -2;
     launch_resolve_display(c->accum, c->W * c->H, P->isRendering ? P->frameIndex + 1 : 1, c->display, c->stream);
     HIP_TRY(hipGetLastError());
     if (P->pixelBuffer) HIP_TRY(hipMemcpyAsync(P->pixelBuffer, c->display, (size_t)c->W * c->H * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1145,6 +1223,7 @@ int pt_trace_closest_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* hits_
 // wavefront renderer's extend stage runs. Device pointers.
 int pt_trace_closest_fast_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* hits_dev)
 {
+    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     int rc = check_ready(c, false);
     if (rc != PT_OK) return rc;
     if (n <= 0 || !rays_dev || !hits_dev) { set_error("pt_trace_closest_fast_dev: bad argument"); return PT_ERR_ARG; }

@@ -12,7 +12,7 @@ void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, h
 void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t ext0, hipEvent_t ext1);
 void launch_wf_repack(const WfParams& src, const WfParams& dst, hipStream_t s);
 void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int max_paths, DCounters* ctr, hipStream_t s);
-void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, hipStream_t s);
+void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, int first, int count, hipStream_t s);
 void launch_wf_trace(const WfParams& w, const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, hipStream_t s);
 int gpu_build_lbvh(const pt_triangle* tris_dev, int n, pt_bvh_node* nodes_dev, int* tri_idx_dev, hipStream_t stream);
 void launch_env_tables(const float* cdf_dev, int w, int h, float* row_table_dev, float* col_table_dev, hipStream_t stream);

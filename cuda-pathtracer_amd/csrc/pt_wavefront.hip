@@ -806,7 +806,7 @@ __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, 
 // ---------------------------------------------------------------- accumulate
 // pathtracer.cu:583-586 over the chunk: per pixel, frames in order; the channel a sample went to is
 // re-derived from its random stream (draw 2, or 4 with the thin lens: pathtracer.cu:562,577,527).
-__global__ __launch_bounds__(kBlock) void wf_accumulate_kernel(WfParams w, DCamera cam, float* __restrict__ accum)
+__global__ __launch_bounds__(kBlock) void wf_accumulate_kernel(WfParams w, DCamera cam, float* __restrict__ accum, int first, int count)
 {
     uint32_t q = blockIdx.x * kBlock + threadIdx.x;
     if (q >= w.n_pixels) return;
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate_kernel(WfParams w, DCame
     uint32_t p = (uint32_t)(x + y * w.W);
     F3 acc = f3(accum[3 * (size_t)p], accum[3 * (size_t)p + 1], accum[3 * (size_t)p + 2]);
     uint32_t ch_draw = cam.dof > 0.f ? 4u : 2u;
-    for (int f = 0; f < w.n_frames; f++) {
+    for (int f = first; f < first + count; f++) {
         float v = w.staging[(size_t)f * w.n_pixels + q];
         Rng g;
         rng_seed(g, p, (uint32_t)(w.frame_begin + f), ch_draw);
@@ -999,9 +999,10 @@ void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int
     else hipLaunchKernelGGL((wf_drain_kernel<false, false>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
 }
 
-void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, hipStream_t s)
+// adds frames [first, first + count) of the lane's staged chunk to its pixels
+void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, int first, int count, hipStream_t s)
 {
-    hipLaunchKernelGGL(wf_accumulate_kernel, dim3((w.n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, w, cam, accum_dev);
+    hipLaunchKernelGGL(wf_accumulate_kernel, dim3((w.n_pixels + kBlock - 1) / kBlock), dim3(kBlock), 0, s, w, cam, accum_dev, first, count);
 }
 
 } // namespace ptamd

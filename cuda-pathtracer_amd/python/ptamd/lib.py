@@ -19,7 +19,7 @@ PT_MODE_WAVEFRONT, PT_MODE_SINGLE_KERNEL = 0, 1
 
 EXPORTS = [
     'pt_last_error', 'pt_create', 'pt_destroy', 'pt_set_stream', 'pt_init', 'pt_clear_accum', 'pt_upload_triangles',
-    'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_upload_texture', 'pt_upload_envmap',
+    'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_set_frame_lookahead', 'pt_upload_texture', 'pt_upload_envmap',
     'pt_set_sky_mode', 'pt_set_env_guides', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_set_repack', 'pt_wavefront_stats', 'pt_set_lanes', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
     'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_save_exr', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
     'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
@@ -247,6 +247,9 @@ class Renderer:
 
     def set_pool(self, slots, chunk_frames=64):
         check(lib().pt_set_pool(self.h, C.c_int(slots), C.c_int(chunk_frames)))
+
+    def set_frame_lookahead(self, max_frames):
+        check(lib().pt_set_frame_lookahead(self.h, C.c_int(max_frames)))
 
     def set_repack(self, percent):
         check(lib().pt_set_repack(self.h, C.c_int(percent)))

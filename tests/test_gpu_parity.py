@@ -244,6 +244,36 @@ def test_frame_ranges_compose():
     r.close()
 
 
+def test_frames_rendered_ahead_arrive_in_order():
+    """pt_render_frame renders 2, 4, ... frames per batch while the caller keeps asking for the next frame of one view
+    and adds each to the accumulator when its call comes. Every call must return the image and leave the accumulator
+    of the one-frame-per-call loop: through batches, a change of view, a restart at frame 0, a change of the bounce
+    cap between calls (staged frames become stale) and a skipped frame index."""
+    b = util.atrium(detail=0.3, env_size=(64, 32))
+    P = scenes.atrium_params(ptamd.default_params(72, 40))
+    plain, ahead = b.renderer(P), b.renderer(P)
+    plain.set_frame_lookahead(1)
+    ahead.set_frame_lookahead(8)
+    for r in (plain, ahead):
+        r.set_max_bounces(8)
+    script = [('f', k) for k in range(14)] + [('move', 0)] + [('f', k) for k in range(5)] + [('bounces', 5)] + [('f', k) for k in range(5, 9)] + \
+             [('f', 11), ('f', 12), ('f', 13), ('f', 0), ('f', 1), ('f', 2)]
+    for op, k in script:
+        if op == 'move':
+            P.rayOrigin.x += 25.0
+            continue
+        if op == 'bounces':
+            plain.set_max_bounces(k); ahead.set_max_bounces(k)
+            continue
+        P.frameIndex = k
+        a = plain.render_frame(P)
+        c = ahead.render_frame(P)
+        assert np.array_equal(a, c), ('image', k)
+        assert np.array_equal(bits(plain.read_accum()), bits(ahead.read_accum())), ('accumulator', k)
+    assert ahead.wavefront_stats()['iterations'] < plain.wavefront_stats()['iterations']
+    plain.close(); ahead.close()
+
+
 def test_small_pools_repeat_exactly():
     """Slot regeneration near the end of a render (slots retiring while other workgroups still hold unissued
     sample ids) must not depend on scheduling: the same render ten times gives the same bits."""
