@@ -375,6 +375,15 @@ def test_full_size_render_properties():
     r.clear_accum()
     r.render(P, 0, 3)
     assert np.array_equal(bits(r.read_accum()), bits(wave))
+    # 25 million samples: slots are reused many times, both lanes run, the pool is repacked and drained
+    r.clear_accum()
+    r.render(P, 0, 12)
+    single = r.read_accum()
+    r.set_mode(0)
+    r.clear_accum()
+    r.render(P, 0, 12)
+    assert np.array_equal(bits(r.read_accum()), bits(single))
+    assert r.wavefront_stats()['repacks'] >= 1
     r.close()
     assert np.isfinite(wave).all() and wave.min() >= 0 and wave.mean() > 0.01
     # oracle on a sparse sample of pixels (a few hundred single-pixel evaluations)
