@@ -4,7 +4,7 @@
  * Nothing in the shipped library includes, links or calls this file.  Only the
  * test-suite, the smoke check and the benchmark's cpu_baseline leg load it.
  *
- * It restates, function by function, what "Cuda Pathtracer/core/CUDA/*" and
+ * It restates, function by function, what the files under "Cuda Pathtracer/core/CUDA" and
  * "core/BVH/BVH_builder.cpp" of the reference compute, in scalar host C++ with the
  * reference's operand types (float where the reference is float, double where a
  * double literal promotes a sub-expression) and its operation order.  Each function
