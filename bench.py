@@ -175,6 +175,7 @@ def main():
         achieved = alg_per_launch / (kms * 1e-3) / 1e9
         node_b, tri_b = r.scene_bytes()
         traffic = None
+        valu = {}
         pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc_path):
             try:
@@ -182,6 +183,7 @@ def main():
                     pm = json.load(f)
                 if pm.get('workload') == [W, H, spp, args.bounces]:
                     traffic = pm.get('hbm_bytes_per_launch')
+                    valu = {k: pm[k] for k in ('valu_busy', 'valu_lanes_per_instruction', 'valu_note') if k in pm}
             except Exception:
                 traffic = None
         result = {
@@ -200,7 +202,7 @@ def main():
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'kernel_ms': round(kms, 4),
                          'note': 'algorithmic bytes = 40 per ray + 32 per box test + 48 per triangle test of the reference-order traversal (counted); the scene is cache resident and the kernel walks 4-wide nodes, so fewer bytes reach HBM (traffic) and frac can exceed 1',
-                         'whole_path_algorithmic_GBs': round(algorithmic_bytes(loc) / (elapsed * 1e9), 2), 'algorithmic_bytes_per_launch': int(alg_per_launch)},
+                         'whole_path_algorithmic_GBs': round(algorithmic_bytes(loc) / (elapsed * 1e9), 2), 'algorithmic_bytes_per_launch': int(alg_per_launch), **valu},
         }
 
     # CPU baseline: the oracle on this host's cores, rank 0, single-GPU runs only, bounded sample
