@@ -311,6 +311,9 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
 //          tests, which then equal the oracle's counts.
 //   WIDE:  walks the 4-wide quantized nodes (closest hits do not depend on the visiting order).
 //   neither: the binary quantized nodes, for trees too deep for the 4-wide stack.
+#ifndef PT_SKIP_ROOT_TEST
+#define PT_SKIP_ROOT_TEST 1
+#endif
 #ifndef PT_TAIL_FACTOR
 #define PT_TAIL_FACTOR 2u
 #endif
@@ -548,8 +551,16 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                 if (QUANT) inv = f3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
                 else inv = 1.0f / d;
                 if (COUNT) tl.box += 1;
-                float troot = box_entry(o, inv, S.root_min, S.root_max);
-                if (troot < best.t) cur = WIDE ? S.root_ref4 : S.root_ref;
+#if PT_SKIP_ROOT_TEST
+                // the 4-wide walk starts at the root node without testing the scene box: the root's child boxes cull
+                // a ray that misses the scene in one step, and nearly every ray of a render starts inside it
+                if (WIDE && S.root_ref4 >= 0) cur = S.root_ref4;
+                else
+#endif
+                {
+                    float troot = box_entry(o, inv, S.root_min, S.root_max);
+                    if (troot < best.t) cur = WIDE ? S.root_ref4 : S.root_ref;
+                }
                 if (QUANT) {
                     oq = (o - ld3(S.q_origin)) * ld3(S.q_inv_cell);
                     invq = inv * ld3(S.q_cell);
