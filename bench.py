@@ -49,6 +49,7 @@ def main():
     ap.add_argument('--cpu-spp', type=int, default=12, help='frames the CPU oracle renders for the baseline (about 15 s on 16 cores)')
     ap.add_argument('--mode', choices=['wavefront', 'single_kernel'], default='wavefront')
     ap.add_argument('--pool', type=int, default=0, help='wavefront pool slots (0 = library default)')
+    ap.add_argument('--chunk-frames', type=int, default=0, help='frames per staging chunk (0 = library default)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl is RCCL; gloo lets several ranks rehearse on one GPU)')
     ap.add_argument('--device', type=int, default=-1, help='GPU to use (default: LOCAL_RANK)')
     ap.add_argument('--fp32-textures', action='store_true', help='keep 8-bit textures as fp32 texels instead of bytes')
@@ -91,8 +92,8 @@ def main():
     r = bundle.renderer(P, device, pack_textures=not args.fp32_textures)
     r.set_max_bounces(args.bounces)
     r.set_mode(0 if args.mode == 'wavefront' else 1)
-    if args.pool:
-        r.set_pool(args.pool, 64)
+    if args.pool or args.chunk_frames:
+        r.set_pool(args.pool or (1 << 24), args.chunk_frames or 512)
     r.set_node_width(args.node_width)
     if args.drain >= 0:
         r.set_drain(args.drain)

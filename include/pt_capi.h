@@ -174,7 +174,7 @@ int pt_set_env_guides(pt_ctx* ctx, int on, int* verified_out);           /* on (
 
 /* ---- headless rendering (replaces the window loop, main.cpp:247-296) ---- */
 int pt_set_mode(pt_ctx* ctx, int mode);                                 /* PT_MODE_*; both modes give identical accumulators */
-int pt_set_pool(pt_ctx* ctx, int slots, int chunk_frames);              /* wavefront pool size and frames per staging chunk */
+int pt_set_pool(pt_ctx* ctx, int slots, int chunk_frames);              /* wavefront pool size (default 16777216 path slots) and frames per staging chunk (default 512; one float per pixel and frame of a chunk is held, and each chunk pays one ramp-up and run-down of the pool) */
 int pt_set_drain(pt_ctx* ctx, int max_rays);                            /* wavefront mode: once every sample is started and at most max_rays paths remain, finish them in one kernel (0 = never) */
 int pt_set_repack(pt_ctx* ctx, int percent);                            /* wavefront mode: once every sample is started, move the live path slots together whenever they fill at most this percentage of the pool (0 = never, default 50); same accumulator bits */
 int pt_wavefront_stats(pt_ctx* ctx, uint64_t* iterations_out, uint64_t* repacks_out); /* wavefront mode: stage-kernel iterations issued and pool repacks done since the context was created (either pointer may be null) */
