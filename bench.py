@@ -105,7 +105,12 @@ def main():
         r.set_env_guides(args.env_guides)
     if args.tune:
         r.set_extend_tuning(*[int(x) for x in args.tune.split(',')])
-    stream = torch.cuda.current_stream()
+    # Everything of a step (clear, render, reduce, resolve) is ordered on one explicit stream that both torch
+    # and the library use. torch's default stream has handle 0, which the library would read as "use the
+    # context's own stream": the clear and the RCCL reduce would then not be ordered with the render.
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    assert stream.cuda_stream != 0
     r.set_stream(stream.cuda_stream)
     accum = torch.zeros((H, W, 3), dtype=torch.float32, device='cuda')
     r.bind_accum(accum.data_ptr())

@@ -25,6 +25,17 @@ using namespace ptamd;
         }                                                                                     \
     } while (0)
 
+// Device allocation that is released on every way out of a function.
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 struct pt_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -511,16 +522,26 @@ int pt_build_bvh(pt_ctx* c, int flavour)
         if (hipMalloc((void**)&d_idx, (size_t)n * sizeof(int)) != hipSuccess) { (void)hipFree(d_nodes); set_error("pt_build_bvh: out of device memory"); return PT_ERR_NOMEM; }
         int rc = gpu_build_lbvh(c->d_tri_ref, n, d_nodes, d_idx, c->stream);
         if (rc == PT_OK && hipMemcpy(nodes.data(), d_nodes, ((size_t)2 * n - 1) * sizeof(pt_bvh_node), hipMemcpyDeviceToHost) != hipSuccess) { set_error("pt_build_bvh: copy failed"); rc = PT_ERR_HIP; }
-        if (rc == PT_OK && hipMemcpy(c->tri_idx.data(), d_idx, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { set_error("pt_build_bvh: copy failed"); rc = PT_ERR_HIP; }
+        std::vector<int> new_idx((size_t)n);
+        if (rc == PT_OK && hipMemcpy(new_idx.data(), d_idx, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { set_error("pt_build_bvh: copy failed"); rc = PT_ERR_HIP; }
         (void)hipFree(d_nodes); (void)hipFree(d_idx);
         if (rc != PT_OK) return rc;
-        return pt_upload_bvh(c, nodes.data(), 0, 2 * n - 1, n);
+        for (int i = 0; i < n; i++) if (new_idx[i] < 0 || new_idx[i] >= n) { set_error("pt_build_bvh: the device build returned a bad index"); return PT_ERR_HIP; }
+        // the index array and the device tree change together or not at all
+        c->tri_idx.swap(new_idx);
+        rc = pt_upload_bvh(c, nodes.data(), 0, 2 * n - 1, n);
+        if (rc != PT_OK) c->tri_idx.swap(new_idx);
+        return rc;
     }
-    for (int i = 0; i < n; i++) c->tri_idx[i] = i;
+    std::vector<int> new_idx((size_t)n);
+    for (int i = 0; i < n; i++) new_idx[i] = i;
     int used = 0;
-    int rc = build_bvh_reference(c->tris.data(), c->tri_idx.data(), n, nodes.data(), &used);
+    int rc = build_bvh_reference(c->tris.data(), new_idx.data(), n, nodes.data(), &used);
     if (rc != PT_OK) return rc;
-    return pt_upload_bvh(c, nodes.data(), 0, used, n);
+    c->tri_idx.swap(new_idx);
+    rc = pt_upload_bvh(c, nodes.data(), 0, used, n);
+    if (rc != PT_OK) c->tri_idx.swap(new_idx);
+    return rc;
 }
 
 int pt_upload_texture(pt_ctx* c, const float* texels, int w, int h, int comps, uint64_t* handle_out)
@@ -567,13 +588,14 @@ int pt_unorm8_probe(pt_ctx* c, float* out256)
 {
     if (!c || !out256) { set_error("pt_unorm8_probe: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
-    float* d = nullptr;
-    HIP_TRY(hipMalloc((void**)&d, 256 * sizeof(float)));
-    launch_unorm8_probe(d, c->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(out256, d, 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    (void)hipFree(d);
+    DevBuf d;
+    HIP_TRY(d.alloc(256 * sizeof(float)));
+    launch_unorm8_probe(d.as<float>(), c->stream);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out256, d.p, 256 * sizeof(float), hipMemcpyDeviceToHost, c->stream);
+    hipError_t es = hipStreamSynchronize(c->stream);        // nothing may still use the buffer when it is freed
+    HIP_TRY(e);
+    HIP_TRY(es);
     return PT_OK;
 }
 
@@ -582,6 +604,7 @@ int pt_upload_envmap(pt_ctx* c, const float* rgba, const float* cdf, int w, int 
     if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !rgba || !cdf || w <= 0 || h <= 0) { set_error("pt_upload_envmap: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
+    c->have_env = false;            // until the whole upload has succeeded; every buffer below belongs to the context
     if (c->d_env) { (void)hipFree(c->d_env); c->d_env = nullptr; }
     if (c->d_cdf) { (void)hipFree(c->d_cdf); c->d_cdf = nullptr; }
     HIP_TRY(hipMalloc((void**)&c->d_env, (size_t)w * h * 4 * sizeof(float)));
@@ -860,12 +883,37 @@ static int lane_issue_batch(pt_ctx* c, pt_ctx::WfLane& L, const DCamera& cam, DC
 // Frames [f0, f1) through the stage kernels, in chunks that bound the staging memory. The lanes own disjoint
 // pixels (blocks of 64 dealt in turn) and each adds its staged samples to its pixels frame by frame, so every
 // pixel sees its additions in frame order whatever the lanes' timing was.
+// Frames one staging chunk holds: pt_set_pool's chunk_frames, halved until a chunk is at most 2^30 samples
+// (4 GiB of staging).
+static int effective_chunk_frames(const pt_ctx* c)
+{
+    size_t npix = (size_t)c->W * c->H;
+    int max_chunk = c->chunk_frames;
+    while (max_chunk > 1 && npix * (size_t)max_chunk > ((size_t)1 << 30)) max_chunk /= 2;
+    return max_chunk;
+}
+
+static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1, bool hold, int* lanes_used);
+
+// hold: leave the samples in the staging arrays instead of adding them to the accumulator (the caller adds
+// frames one by one); the range must then fit one staging chunk, because every chunk overwrites the last.
 static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1, bool hold = false, int* lanes_used = nullptr)
 {
     c->ahead.valid = false;         // the staging arrays are about to be overwritten
+    if (hold && f1 - f0 > effective_chunk_frames(c)) { set_error("render_wavefront: %d held frames exceed the staging chunk of %d", f1 - f0, effective_chunk_frames(c)); return PT_ERR_ARG; }
+    int rc = render_wavefront_chunks(c, cam, f0, f1, hold, lanes_used);
+    if (rc != PT_OK) {
+        // kernels of either lane may still be queued on buffers a later call resizes or frees
+        for (int i = 0; i < pt_ctx::kMaxLanes; i++) if (c->lanes[i].stream) (void)hipStreamSynchronize(c->lanes[i].stream);
+        c->ahead.valid = false;
+    }
+    return rc;
+}
+
+static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1, bool hold, int* lanes_used)
+{
     size_t npix = (size_t)c->W * c->H;
-    int max_chunk = c->chunk_frames;
-    while (max_chunk > 1 && npix * (size_t)max_chunk > ((size_t)1 << 30)) max_chunk /= 2;     // at most 2^30 samples (4 GiB of staging)
+    const int max_chunk = effective_chunk_frames(c);
     DCounters* ctr = c->counting ? c->d_ctr : nullptr;
     if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     c->lanes[0].stream = c->stream;
@@ -1106,6 +1154,9 @@ int pt_render_frame(pt_ctx* c, pt_params* P)
     if (can_stage && !staged && A.streak >= 1) {
         int k = 1 << (A.streak < 6 ? A.streak : 6);
         k = k < c->lookahead_max ? k : c->lookahead_max;
+        // a batch must stay within one staging chunk: a later chunk would overwrite the frames staged before it
+        const int chunk = effective_chunk_frames(c);
+        k = k < chunk ? k : chunk;
         if ((rc = make_camera(c, P, &cam)) != PT_OK) return rc;
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
         int lanes = 0;
@@ -1244,17 +1295,15 @@ int pt_trace_closest_fast(pt_ctx* c, const pt_ray* rays, int n, pt_hit* hits)
 {
     if (!c || n <= 0 || !rays || !hits) { set_error("pt_trace_closest_fast: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
-    pt_ray* d_r = nullptr; pt_hit* d_h = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_r, (size_t)n * sizeof(pt_ray)));
-    HIP_TRY(hipMalloc((void**)&d_h, (size_t)n * sizeof(pt_hit)));
-    HIP_TRY(hipMemcpyAsync(d_r, rays, (size_t)n * sizeof(pt_ray), hipMemcpyHostToDevice, c->stream));
-    int rc = pt_trace_closest_fast_dev(c, d_r, n, d_h);
-    if (rc == PT_OK) {
-        HIP_TRY(hipMemcpyAsync(hits, d_h, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost, c->stream));
-        rc = pt_sync(c);
-    }
-    (void)hipFree(d_r); (void)hipFree(d_h);
-    return rc;
+    DevBuf d_r, d_h;
+    HIP_TRY(d_r.alloc((size_t)n * sizeof(pt_ray)));
+    HIP_TRY(d_h.alloc((size_t)n * sizeof(pt_hit)));
+    hipError_t e = hipMemcpyAsync(d_r.p, rays, (size_t)n * sizeof(pt_ray), hipMemcpyHostToDevice, c->stream);
+    int rc = e == hipSuccess ? pt_trace_closest_fast_dev(c, d_r.as<pt_ray>(), n, d_h.as<pt_hit>()) : PT_OK;
+    if (e == hipSuccess && rc == PT_OK) e = hipMemcpyAsync(hits, d_h.p, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost, c->stream);
+    int rs = pt_sync(c);                                    // the stream is idle before the buffers are freed
+    HIP_TRY(e);
+    return rc != PT_OK ? rc : rs;
 }
 
 int pt_trace_closest_counted(pt_ctx* c, const pt_ray* rays, int n, pt_hit* hits, uint32_t* nbox, uint32_t* ntri)
@@ -1265,24 +1314,27 @@ int pt_trace_closest_counted(pt_ctx* c, const pt_ray* rays, int n, pt_hit* hits,
     if ((nbox == nullptr) != (ntri == nullptr)) { set_error("pt_trace_closest_counted: pass both counter arrays or neither"); return PT_ERR_ARG; }
     if (n == 0) return PT_OK;
     HIP_TRY(hipSetDevice(c->device));
-    pt_ray* d_r = nullptr; pt_hit* d_h = nullptr; uint32_t* d_b = nullptr; uint32_t* d_t = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_r, (size_t)n * sizeof(pt_ray)));
-    HIP_TRY(hipMalloc((void**)&d_h, (size_t)n * sizeof(pt_hit)));
-    if (nbox) { HIP_TRY(hipMalloc((void**)&d_b, (size_t)n * 4)); HIP_TRY(hipMalloc((void**)&d_t, (size_t)n * 4)); }
-    HIP_TRY(hipMemcpyAsync(d_r, rays, (size_t)n * sizeof(pt_ray), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    launch_trace_closest(c->scene, d_r, n, d_h, d_b, d_t, c->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipMemcpyAsync(hits, d_h, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost, c->stream));
-    if (nbox) {
-        HIP_TRY(hipMemcpyAsync(nbox, d_b, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipMemcpyAsync(ntri, d_t, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-    }
-    rc = pt_sync(c);
-    (void)hipFree(d_r); (void)hipFree(d_h);
-    if (d_b) (void)hipFree(d_b);
-    if (d_t) (void)hipFree(d_t);
+    DevBuf d_r, d_h, d_b, d_t;
+    HIP_TRY(d_r.alloc((size_t)n * sizeof(pt_ray)));
+    HIP_TRY(d_h.alloc((size_t)n * sizeof(pt_hit)));
+    if (nbox) { HIP_TRY(d_b.alloc((size_t)n * 4)); HIP_TRY(d_t.alloc((size_t)n * 4)); }
+    auto run = [&]() -> hipError_t {
+        hipError_t e;
+        if ((e = hipMemcpyAsync(d_r.p, rays, (size_t)n * sizeof(pt_ray), hipMemcpyHostToDevice, c->stream)) != hipSuccess) return e;
+        if ((e = hipEventRecord(c->ev0, c->stream)) != hipSuccess) return e;
+        launch_trace_closest(c->scene, d_r.as<pt_ray>(), n, d_h.as<pt_hit>(), d_b.as<uint32_t>(), d_t.as<uint32_t>(), c->stream);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+        if ((e = hipEventRecord(c->ev1, c->stream)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(hits, d_h.p, (size_t)n * sizeof(pt_hit), hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+        if (nbox) {
+            if ((e = hipMemcpyAsync(nbox, d_b.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+            if ((e = hipMemcpyAsync(ntri, d_t.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream)) != hipSuccess) return e;
+        }
+        return hipSuccess;
+    };
+    hipError_t e = run();
+    rc = pt_sync(c);                                        // the stream is idle before the buffers are freed
+    HIP_TRY(e);
     return rc;
 }
 
@@ -1317,17 +1369,18 @@ int pt_detmath_probe(pt_ctx* c, const float* x, const float* y, int n, float* ou
 {
     if (!c || !x || !y || !out || n <= 0) { set_error("pt_detmath_probe: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
-    float *dx = nullptr, *dy = nullptr, *dout = nullptr;
-    HIP_TRY(hipMalloc((void**)&dx, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void**)&dy, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void**)&dout, (size_t)n * 48));
-    HIP_TRY(hipMemcpy(dx, x, (size_t)n * 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(dy, y, (size_t)n * 4, hipMemcpyHostToDevice));
-    launch_detmath_probe(dx, dy, n, dout, c->stream);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy(out, dout, (size_t)n * 48, hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(dout);
+    DevBuf dx, dy, dout;
+    HIP_TRY(dx.alloc((size_t)n * 4));
+    HIP_TRY(dy.alloc((size_t)n * 4));
+    HIP_TRY(dout.alloc((size_t)n * 48));
+    HIP_TRY(hipMemcpy(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dy.p, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_detmath_probe(dx.as<float>(), dy.as<float>(), n, dout.as<float>(), c->stream);
+    hipError_t e = hipGetLastError();
+    hipError_t es = hipStreamSynchronize(c->stream);        // nothing may still use the buffers when they are freed
+    HIP_TRY(e);
+    HIP_TRY(es);
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)n * 48, hipMemcpyDeviceToHost));
     return PT_OK;
 }
 

@@ -25,8 +25,14 @@ struct Huff {
     uint8_t vals[256];
     int mincode[17], maxcode[18], valptr[17];
     uint16_t look[512];         // 9-bit prefix -> (length << 8 | value), 0 = longer code
-    void build(const uint8_t* bits, const uint8_t* v, int n)
+    // false when the code lengths over-subscribe the code space (more codes of some length than prefixes
+    // are left: the Kraft inequality), which would index past the tables below
+    bool build(const uint8_t* bits, const uint8_t* v, int n)
     {
+        for (int len = 1, code = 0; len <= 16; len++) {
+            if (code + (int)bits[len - 1] > (1 << len)) return false;
+            code = (code + (int)bits[len - 1]) << 1;
+        }
         present = true;
         memcpy(vals, v, (size_t)n);
         int code = 0, k = 0;
@@ -43,6 +49,7 @@ struct Huff {
             code <<= 1;
         }
         maxcode[17] = 0x7fffffff;
+        return true;
     }
 };
 
@@ -361,7 +368,7 @@ struct Decoder {
                     int tc = p[i] >> 4, th = p[i] & 15, cnt = 0;
                     for (int k = 0; k < 16; k++) cnt += p[i + 1 + k];
                     if (tc > 1 || th > 3 || cnt > 256 || i + 17 + cnt > n) { err = "bad Huffman table"; return false; }
-                    (tc ? ac[th] : dc[th]).build(p + i + 1, p + i + 17, cnt);
+                    if (!(tc ? ac[th] : dc[th]).build(p + i + 1, p + i + 17, cnt)) { err = "bad Huffman table"; return false; }
                     i += 17 + cnt;
                 }
             } else if (m == 0xC0 || m == 0xC1 || m == 0xC2) {

@@ -334,44 +334,65 @@ int read_obj_general(const char* obj_path, const char* model_dir, const char* su
     return PT_OK;
 }
 
-// ---------------------------------------------------------------- Radiance RGBE, hdr_loader.h:47-281
+// ---------------------------------------------------------------- Radiance RGBE (the format hdr_loader.h:47-281 reads)
+// The file is read whole and decoded from memory with every access bounds-checked. What is accepted matches
+// the reference's reader: a "#?" signature line, FORMAT=32-bit_rle_rgbe|xyze, a resolution line "-Y h +X w",
+// then h scanlines, each either flat (4 bytes per pixel) or new-style run-length coded per component (marker
+// 2 2 hi lo with hi:lo == w, only for 8 <= w <= 32767); a pixel is (mantissa + 0.5) * 2^(e - 136), zero when e == 0.
 namespace {
-bool starts(const char* line, const char* id, const char** rest)
+struct Bytes {
+    const uint8_t* p; const uint8_t* end;
+    size_t left() const { return (size_t)(end - p); }
+    // next text line without its terminator; false at the end of the data
+    bool line(std::string& out)
+    {
+        if (p >= end) return false;
+        const uint8_t* nl = (const uint8_t*)memchr(p, '\n', left());
+        const uint8_t* stop = nl ? nl : end;
+        out.assign((const char*)p, (size_t)(stop - p));
+        p = nl ? nl + 1 : end;
+        return true;
+    }
+};
+
+// the unsigned number that follows the axis letter on the resolution line
+bool axis_size(const std::string& line, char axis, unsigned* out)
 {
-    size_t l = strlen(id);
-    if (strncmp(line, id, l) != 0) return false;
-    *rest = line + l;
+    size_t at = line.find(axis);
+    if (at == std::string::npos || at == 0) return false;
+    at++;
+    while (at < line.size() && line[at] == ' ') at++;
+    uint64_t v = 0; size_t digits = 0;
+    while (at < line.size() && line[at] >= '0' && line[at] <= '9' && v < (1ull << 32)) { v = v * 10 + (uint64_t)(line[at] - '0'); at++; digits++; }
+    if (digits == 0 || v >= (1ull << 32)) return false;
+    *out = (unsigned)v;
     return true;
 }
-bool read_flat(unsigned char* buf, unsigned len, FILE* fp) { return fread(buf, 4, len, fp) == len; }
-bool read_rle(unsigned char* buf, unsigned len, FILE* fp)      // hdr_loader.h:124-194
+
+// one scanline of `width` pixels into row[4 * width]
+bool scanline(Bytes& in, uint8_t* row, unsigned width, bool may_be_coded)
 {
-    int c = fgetc(fp);
-    if (c == EOF) return false;
-    if (c != 2) { ungetc(c, fp); return read_flat(buf, len, fp); }
-    buf[1] = (unsigned char)fgetc(fp);
-    buf[2] = (unsigned char)fgetc(fp);
-    c = fgetc(fp);
-    if (buf[1] != 2 || (buf[2] & 128)) { buf[0] = 2; buf[3] = (unsigned char)c; return read_flat(buf + 4, len - 1, fp); }
-    unsigned l = (unsigned)buf[2] << 8 | (unsigned)c;
-    if (l != len) return false;
+    const size_t flat = (size_t)width * 4;
+    const bool coded = may_be_coded && in.left() >= 4 && in.p[0] == 2 && in.p[1] == 2 && !(in.p[2] & 128);
+    if (!coded) {
+        if (in.left() < flat) return false;
+        memcpy(row, in.p, flat);
+        in.p += flat;
+        return true;
+    }
+    if ((((unsigned)in.p[2] << 8) | in.p[3]) != width) return false;
+    in.p += 4;
     for (unsigned comp = 0; comp < 4; comp++) {
-        for (unsigned pos = 0; pos < len;) {
-            int num = fgetc(fp);
-            if (num == EOF) return false;
-            if (num > 128) {
-                num &= 127;
-                int val = fgetc(fp);
-                if (val == EOF || pos + num > len) return false;
-                for (int j = 0; j < num; j++) buf[(pos++) * 4 + comp] = (unsigned char)val;
-            } else {
-                if (pos + num > len) return false;
-                for (int j = 0; j < num; j++) {
-                    int val = fgetc(fp);
-                    if (val == EOF) return false;
-                    buf[(pos++) * 4 + comp] = (unsigned char)val;
-                }
-            }
+        unsigned filled = 0;
+        while (filled < width) {
+            if (in.left() < 2) return false;
+            unsigned code = *in.p++;
+            const bool run = code > 128;
+            const unsigned count = run ? code - 128 : code;
+            if (count > width - filled || (!run && in.left() < count)) return false;
+            for (unsigned k = 0; k < count; k++) row[(size_t)(filled + k) * 4 + comp] = run ? in.p[0] : in.p[k];
+            in.p += run ? 1 : count;
+            filled += count;
         }
     }
     return true;
@@ -381,45 +402,46 @@ bool read_rle(unsigned char* buf, unsigned len, FILE* fp)      // hdr_loader.h:1
 int load_hdr(const char* path, float** rgba_out, int* w_out, int* h_out)
 {
     *rgba_out = nullptr; *w_out = *h_out = 0;
-    FILE* fp = fopen(path, "rb");
-    if (!fp) { set_error("cannot open %s", path); return PT_ERR_IO; }
-    char line[2048];
-    unsigned rx = 0, ry = 0;
-    if (!fgets(line, sizeof(line), fp) || (line[0] != '#' && line[1] != '?')) { fclose(fp); set_error("%s: not a Radiance file", path); return PT_ERR_IO; }
+    std::vector<uint8_t> file;
+    {
+        FILE* fp = fopen(path, "rb");
+        if (!fp) { set_error("cannot open %s", path); return PT_ERR_IO; }
+        uint8_t chunk[1 << 16];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof(chunk), fp)) > 0) file.insert(file.end(), chunk, chunk + got);
+        fclose(fp);
+    }
+    Bytes in{file.data(), file.data() + file.size()};
+    std::string text;
+    if (!in.line(text) || (text.size() < 2) || (text[0] != '#' && text[1] != '?')) { set_error("%s: not a Radiance file", path); return PT_ERR_IO; }
+    unsigned width = 0, height = 0;
     for (;;) {
-        if (!fgets(line, sizeof(line), fp)) { fclose(fp); set_error("%s: truncated header", path); return PT_ERR_IO; }
-        if (line[0] == '#') continue;
-        const char* rest;
-        if (starts(line, "FORMAT=", &rest)) {
-            if (strncmp(rest, "32-bit_rle_xyze", 15) != 0 && strncmp(rest, "32-bit_rle_rgbe", 15) != 0) { fclose(fp); set_error("%s: unknown FORMAT", path); return PT_ERR_IO; }
-        } else if (line[0] == '-' || line[0] == '+') {
-            const char* x = strchr(line, 'X');
-            const char* y = strchr(line, 'Y');
-            if (!x || x <= line || sscanf(x + 1, "%u", &rx) != 1 || !y || y <= line || sscanf(y + 1, "%u", &ry) != 1) { fclose(fp); set_error("%s: bad resolution line", path); return PT_ERR_IO; }
+        if (!in.line(text)) { set_error("%s: truncated header", path); return PT_ERR_IO; }
+        if (text.empty() || text[0] == '#') continue;
+        if (text.compare(0, 7, "FORMAT=") == 0) {
+            if (text.compare(7, 15, "32-bit_rle_xyze") != 0 && text.compare(7, 15, "32-bit_rle_rgbe") != 0) { set_error("%s: unknown FORMAT", path); return PT_ERR_IO; }
+        } else if (text[0] == '-' || text[0] == '+') {
+            if (!axis_size(text, 'X', &width) || !axis_size(text, 'Y', &height)) { set_error("%s: bad resolution line", path); return PT_ERR_IO; }
             break;
         }
     }
-    if (rx == 0 || ry == 0 || (uint64_t)rx * ry > (1ull << 30)) { fclose(fp); set_error("%s: bad size", path); return PT_ERR_IO; }
-    float* px = (float*)calloc((size_t)rx * ry, 4 * sizeof(float));
-    unsigned char* buf = (unsigned char*)malloc((size_t)rx * 4);
-    if (!px || !buf) { free(px); free(buf); fclose(fp); set_error("out of memory"); return PT_ERR_NOMEM; }
-    const bool rle = !(rx < 8 || rx > 0x7fff);
-    for (unsigned j = 0; j < ry; j++) {
-        bool ok = rle ? read_rle(buf, rx, fp) : read_flat(buf, rx, fp);
-        if (!ok) { free(px); free(buf); fclose(fp); set_error("%s: pixel data truncated", path); return PT_ERR_IO; }
-        for (unsigned i = 0; i < rx; i++) {
-            const unsigned char* e = buf + 4 * i;
-            float* o = px + 4 * ((size_t)j * rx + i);
-            if (e[3] == 0) { o[0] = o[1] = o[2] = 0.f; }
-            else {
-                uint32_t bits = (uint32_t)(((int)e[3] - 9) << 23) & 0x7f800000u;   // hdr_loader.h:210
-                float sc; memcpy(&sc, &bits, 4);
-                o[0] = (float)(e[0] + 0.5f) * sc; o[1] = (float)(e[1] + 0.5f) * sc; o[2] = (float)(e[2] + 0.5f) * sc;
-            }
+    if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 30)) { set_error("%s: bad size", path); return PT_ERR_IO; }
+    float* px = (float*)calloc((size_t)width * height, 4 * sizeof(float));
+    if (!px) { set_error("out of memory"); return PT_ERR_NOMEM; }
+    std::vector<uint8_t> row((size_t)width * 4);
+    const bool may_be_coded = width >= 8 && width <= 0x7fff;
+    for (unsigned y = 0; y < height; y++) {
+        if (!scanline(in, row.data(), width, may_be_coded)) { free(px); set_error("%s: pixel data truncated", path); return PT_ERR_IO; }
+        float* out = px + 4 * (size_t)y * width;
+        for (unsigned x = 0; x < width; x++, out += 4) {
+            const uint8_t* e = &row[4 * (size_t)x];
+            if (e[3] == 0) continue;                                              // calloc left the pixel black
+            uint32_t scale_bits = (uint32_t)(((int)e[3] - 9) << 23) & 0x7f800000u;    // 2^(e - 136) (hdr_loader.h:210)
+            float scale; memcpy(&scale, &scale_bits, 4);
+            out[0] = (float)(e[0] + 0.5f) * scale; out[1] = (float)(e[1] + 0.5f) * scale; out[2] = (float)(e[2] + 0.5f) * scale;
         }
     }
-    free(buf); fclose(fp);
-    *rgba_out = px; *w_out = (int)rx; *h_out = (int)ry;
+    *rgba_out = px; *w_out = (int)width; *h_out = (int)height;
     return PT_OK;
 }
 

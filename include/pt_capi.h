@@ -182,7 +182,7 @@ int pt_set_lanes(pt_ctx* ctx, int lanes);                                /* wave
 int pt_set_extend_tuning(pt_ctx* ctx, int refill_lanes, int leaf_vote, int blocks_per_cu); /* traversal kernel: idle lanes before a refill, lanes waiting at leaves before a leaf pass, resident workgroups per CU */
 int pt_set_node_width(pt_ctx* ctx, int width, int leaf_merge);         /* production traversal: 4-wide (default) or binary compact nodes; subtrees of <= leaf_merge triangles (default 2) become one wide leaf at the next BVH upload; a tree too deep for the 4-wide stack uses binary */
 int pt_set_max_bounces(pt_ctx* ctx, int max_bounces);                   /* pathtracer.cu:405 hard-codes 512 */
-int pt_render_headless(pt_ctx* ctx, const pt_params* params, int frame_begin, int frame_end); /* frames [begin,end): accum as pathtracer.cu:583-586, first frame overwrites */
+int pt_render_headless(pt_ctx* ctx, const pt_params* params, int frame_begin, int frame_end); /* frames [begin,end) are ADDED to the accumulator in frame order (the += of pathtracer.cu:585-586), also when frame_begin is 0: ranges compose across calls and across GPUs. The overwrite the reference does for frame 0 and for preview frames (pathtracer.cu:583-584) is the caller's pt_clear_accum; pt_render_frame does it itself */
 int pt_read_accum(pt_ctx* ctx, float* rgb_out);                         /* 3*W*H floats */
 int pt_accum_device_ptr(pt_ctx* ctx, float** accum_dev_out);            /* device address of the fp32 accumulator (for collectives) */
 int pt_bind_accum(pt_ctx* ctx, float* accum_dev);                       /* render into a caller-owned device buffer of 3*W*H floats (NULL = the context's own) */
@@ -207,6 +207,7 @@ int pt_get_counters(pt_ctx* ctx, pt_counters* out);
 int pt_reset_counters(pt_ctx* ctx);
 int pt_enable_counters(pt_ctx* ctx, int on);                            /* instrumented kernels (slower); off by default */
 int pt_stage_timing(pt_ctx* ctx, int on, double* extend_ms_out, uint64_t* extend_launches_out); /* HIP-event time of the extend kernel: returns the totals since the last call, then switches timing on/off and clears them */
+int pt_debug_words(pt_ctx* ctx, unsigned long long* out16);                 /* diagnostic builds only: 16 statistics words of the traversal kernel, zeroed on read (all zero in a regular build) */
 int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* tri_bytes); /* size of the flattened BVH in HBM */
 int pt_detmath_probe(pt_ctx* ctx, const float* x, const float* y, int n, float* out12); /* device evaluation of include/pt_detmath.h, 12 results per input pair */
 int pt_unorm8_probe(pt_ctx* ctx, float* out256);                         /* device evaluation of the byte -> float conversion of packed textures */

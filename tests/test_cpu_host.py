@@ -31,6 +31,12 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in names if not hasattr(L, n)]
     assert not missing, missing
     assert sorted(lib.EXPORTS) == names, 'the Python binding list and the header disagree'
+    # and the other way round: the library exports no pt_ function the header does not declare
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(set(re.findall(r'\b[TW] (pt_[a-z0-9_]+)$', out, flags=re.M)))
+    undeclared = [n for n in exported if n not in names]
+    assert not undeclared, undeclared
 
 
 def test_pod_layouts_match_the_reference_structs():
@@ -377,6 +383,16 @@ def test_jpeg_texture_decoder_agrees_with_libjpeg(tmp_path):
         lib.load_texture_image(os.path.join(d, 'noisy.jpg'), 4)
     except ptamd.PtError:
         pass
+    # a Huffman table whose code lengths over-subscribe the code space (255 codes of one bit) is refused
+    base = open(os.path.join(d, '444.jpg'), 'rb').read()
+    at = base.index(b'\xff\xc4')
+    seg_len = int.from_bytes(base[at + 2:at + 4], 'big')
+    bad_counts = bytes([255, 1] + [0] * 14)
+    bad = base[:at + 5] + bad_counts + base[at + 21:]
+    bad = bad[:at + 2] + (2 + 1 + 16 + 256).to_bytes(2, 'big') + bad[at + 4:at + 21] + bytes(256) + bad[at + 2 + seg_len:]
+    open(os.path.join(d, 'dht.jpg'), 'wb').write(bad)
+    with pytest.raises(ptamd.PtError, match='Huffman'):
+        lib.load_texture_image(os.path.join(d, 'dht.jpg'), 4)
     Image.fromarray(a).convert('CMYK').save(os.path.join(d, 'cmyk.jpg'), 'JPEG')
     with pytest.raises(ptamd.PtError):
         lib.load_texture_image(os.path.join(d, 'cmyk.jpg'), 4)

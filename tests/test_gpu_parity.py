@@ -274,6 +274,26 @@ def test_frames_rendered_ahead_arrive_in_order():
     plain.close(); ahead.close()
 
 
+def test_frames_rendered_ahead_stay_within_one_staging_chunk():
+    """A staging chunk smaller than the look-ahead (pt_set_pool's chunk_frames) bounds the batch: every staged frame
+    must still be in the staging arrays when its call comes."""
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(40, 24))
+    plain, ahead = b.renderer(P), b.renderer(P)
+    plain.set_frame_lookahead(1)
+    ahead.set_frame_lookahead(8)
+    ahead.set_pool(512, 2)
+    for r in (plain, ahead):
+        r.set_max_bounces(6)
+    for k in range(12):
+        P.frameIndex = k
+        a = plain.render_frame(P)
+        c = ahead.render_frame(P)
+        assert np.array_equal(a, c), ('image', k)
+        assert np.array_equal(bits(plain.read_accum()), bits(ahead.read_accum())), ('accumulator', k)
+    plain.close(); ahead.close()
+
+
 def test_small_pools_repeat_exactly():
     """Slot regeneration near the end of a render (slots retiring while other workgroups still hold unissued
     sample ids) must not depend on scheduling: the same render ten times gives the same bits."""
