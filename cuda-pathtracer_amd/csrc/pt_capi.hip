@@ -119,6 +119,8 @@ struct pt_ctx {
         int streak = 0;             // consecutive calls that continued the previous one
         int last_frame = -2;
     } ahead;
+    void* static_scratch = nullptr; // this device's copy of the library's built-in block (pt_trace_closest_noalloc_dev)
+    hipError_t static_scratch_error = hipSuccess;
     uint64_t wf_iterations = 0, wf_repacks = 0;
     int repack_percent = 50;        // repack the pool when the live slots are at most this share of it (0: never)
     bool stage_timing = false;
@@ -152,6 +154,9 @@ int pt_create(pt_ctx** out, int device_id)
     HIP_TRY(hipEventCreate(&c->ev1));
     HIP_TRY(hipMalloc((void**)&c->d_ctr, sizeof(DCounters)));
     HIP_TRY(hipMemset(c->d_ctr, 0, sizeof(DCounters)));
+    // the address of the built-in block on this device, looked up here so that the entry point that uses it
+    // has no set-up left to do; a failure is reported by that entry point, everything else works without it
+    c->static_scratch_error = wf_static_scratch(device_id, &c->static_scratch);
     c->scene.sky_mode = PT_SKY_ENVMAP;
     c->scene.sun[0] = 0.f; c->scene.sun[1] = 1.f; c->scene.sun[2] = 0.f;
     *out = c;
@@ -1287,6 +1292,23 @@ int pt_trace_closest_fast_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* 
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     launch_wf_trace(w, c->scene, rays_dev, n, hits_dev, c->stream);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    return PT_OK;
+}
+
+// The same batch with every intermediate in the library's built-in device block: no hipMalloc, hipFree or
+// other allocating call on the way (events and streams were made by pt_create).
+int pt_trace_closest_noalloc_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* hits_dev)
+{
+    int rc = check_ready(c, false);
+    if (rc != PT_OK) return rc;
+    if (n <= 0 || !rays_dev || !hits_dev) { set_error("pt_trace_closest_noalloc_dev: bad argument"); return PT_ERR_ARG; }
+    if (n > PT_NOALLOC_MAX_RAYS) { set_error("pt_trace_closest_noalloc_dev: %d rays exceed the built-in block's %d; split the batch or use pt_trace_closest_fast_dev", n, PT_NOALLOC_MAX_RAYS); return PT_ERR_ARG; }
+    if (!c->static_scratch) { set_error("pt_trace_closest_noalloc_dev: the built-in device block is not available on device %d (%s)", c->device, hipGetErrorString(c->static_scratch_error)); return PT_ERR_STATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(launch_wf_trace_static(c->static_scratch, c->scene, rays_dev, n, hits_dev, c->refill_lanes, c->leaf_vote,
+                                   (c->extend_blocks_per_cu ? c->extend_blocks_per_cu : 5) * c->n_cus, c->stream));
     HIP_TRY(hipEventRecord(c->ev1, c->stream));
     return PT_OK;
 }

@@ -14,6 +14,12 @@ void launch_wf_repack(const WfParams& src, const WfParams& dst, hipStream_t s);
 void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int max_paths, DCounters* ctr, hipStream_t s);
 void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, int first, int count, hipStream_t s);
 void launch_wf_trace(const WfParams& w, const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, hipStream_t s);
+// closest-hit batch over the library's built-in device block (no allocation anywhere on the way)
+constexpr int kStaticMaxRays = PT_NOALLOC_MAX_RAYS;
+constexpr int kStaticMaxDevices = 64;
+hipError_t wf_static_scratch(int device, void** ptr_out);      // `device` must be the current device
+hipError_t launch_wf_trace_static(void* base, const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, int refill_lanes, int leaf_vote,
+                                  int extend_blocks, hipStream_t s);
 int gpu_build_lbvh(const pt_triangle* tris_dev, int n, pt_bvh_node* nodes_dev, int* tri_idx_dev, hipStream_t stream);
 void launch_env_tables(const float* cdf_dev, int w, int h, float* row_table_dev, float* col_table_dev, hipStream_t stream);
 void launch_env_texel_guide(const DScene& S, uint2* guide_dev, uint32_t* mismatches_dev, hipStream_t stream);

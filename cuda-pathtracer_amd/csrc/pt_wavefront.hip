@@ -21,6 +21,7 @@
 // accumulate pass makes the sum independent of scheduling.  Results are therefore bit-identical to
 // the frame loop of the reference (pathtracer.cu:583-586) whatever the pool size or lane count.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include "pt_path.hpp"
 #include "pt_launch.h"
 
@@ -923,6 +924,62 @@ void launch_wf_trace(const WfParams& w, const DScene& S, const pt_ray* rays_dev,
     if (S.wide) hipLaunchKernelGGL((wf_extend_kernel<false, true>), dim3(ext_blocks), block, 0, s, w, S, (DCounters*)nullptr);
     else hipLaunchKernelGGL((wf_extend_kernel<false, false>), dim3(ext_blocks), block, 0, s, w, S, (DCounters*)nullptr);
     hipLaunchKernelGGL(wf_unpack_hits_kernel, grid, block, 0, s, w.hit, n, hits_dev);
+}
+
+// ---------------------------------------------------------------- closest-hit batch without allocations
+// The batch above borrows a slot pool that the library allocates on demand. Callers that must not allocate
+// (code under graph capture, serving loops) get the same kernels over a fixed block of device memory that
+// is part of the library image: ray origins, ray directions and hits of up to kStaticMaxRays rays, the two
+// per-block word arrays of the planning pass, and the counter words.
+constexpr size_t kStaticBlocks = (size_t)kStaticMaxRays / kBlock;
+constexpr size_t kStaticCounterBytes = WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long);
+constexpr size_t kStaticBytes = 3 * (size_t)kStaticMaxRays * sizeof(float4) + 2 * kStaticBlocks * sizeof(uint32_t) + kStaticCounterBytes;
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+// Every GPU holds its own copy of the block at its own address; the address is looked up once per device,
+// with that device current, and kept. Host code never uses the array's name for anything else.
+static std::mutex g_scratch_mutex;
+static void* g_scratch_ptr[kStaticMaxDevices];
+static bool g_scratch_known[kStaticMaxDevices];
+
+hipError_t wf_static_scratch(int device, void** ptr_out)
+{
+    *ptr_out = nullptr;
+    if (device < 0 || device >= kStaticMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_known[device]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        g_scratch_ptr[device] = p;
+        g_scratch_known[device] = true;
+    }
+    *ptr_out = g_scratch_ptr[device];
+    return hipSuccess;
+}
+
+// n <= kStaticMaxRays rays through the production traversal kernel, every intermediate in the block at
+// `base` (what wf_static_scratch returned for the current device). The block keeps the previous call's
+// contents: the pack kernel rewrites the ray arrays and ray counts of every block the launch covers, the
+// planning pass rewrites the block list and the counter words it hands to the traversal kernel, and the
+// counter words are cleared first, so nothing of an earlier call is read.
+hipError_t launch_wf_trace_static(void* base, const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, int refill_lanes, int leaf_vote,
+                                  int extend_blocks, hipStream_t s)
+{
+    if (!base || n <= 0 || n > kStaticMaxRays) return hipErrorInvalidValue;
+    WfParams w{};
+    float4* f = static_cast<float4*>(base);
+    w.ray_o = f; w.ray_d = f + kStaticMaxRays; w.hit = f + 2 * (size_t)kStaticMaxRays;
+    w.chunk_rays = reinterpret_cast<uint32_t*>(f + 3 * (size_t)kStaticMaxRays);
+    w.chunk_list = w.chunk_rays + kStaticBlocks;
+    w.counters = w.chunk_list + kStaticBlocks;
+    w.n_slots = (n + kBlock - 1) / kBlock * kBlock;
+    w.refill_lanes = refill_lanes; w.leaf_vote = leaf_vote; w.extend_blocks = extend_blocks;
+    hipError_t e = hipMemsetAsync(w.counters, 0, kStaticCounterBytes, s);
+    if (e != hipSuccess) return e;
+    launch_wf_trace(w, S, rays_dev, n, hits_dev, s);
+    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------- launchers

@@ -16,13 +16,14 @@ PT_SKY_ENVMAP, PT_SKY_SUNSKY = 0, 1
 PT_BVH_REFERENCE = 0
 PT_BVH_GPU_LBVH = 1
 PT_MODE_WAVEFRONT, PT_MODE_SINGLE_KERNEL = 0, 1
+PT_NOALLOC_MAX_RAYS = 262144     # include/pt_capi.h
 
 EXPORTS = [
     'pt_last_error', 'pt_create', 'pt_destroy', 'pt_set_stream', 'pt_init', 'pt_clear_accum', 'pt_upload_triangles',
     'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_set_frame_lookahead', 'pt_upload_texture', 'pt_upload_envmap',
     'pt_set_sky_mode', 'pt_set_env_guides', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_set_repack', 'pt_wavefront_stats', 'pt_set_lanes', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
     'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_save_exr', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
-    'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_debug_words', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
+    'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_trace_closest_noalloc_dev', 'pt_debug_words', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
     'pt_detmath_probe', 'pt_unorm8_probe', 'pt_set_texture_packing', 'pt_read_obj', 'pt_read_obj_general', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
     'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
     'pt_host_build_bvh', 'pt_load_hdr', 'pt_load_texture_png', 'pt_load_texture_image', 'pt_build_env_cdf', 'pt_free', 'pt_camera_basis',
@@ -348,6 +349,9 @@ class Renderer:
 
     def trace_closest_fast_dev(self, rays_ptr, n, hits_ptr):
         check(lib().pt_trace_closest_fast_dev(self.h, C.c_void_p(rays_ptr), C.c_int(n), C.c_void_p(hits_ptr)))
+
+    def trace_closest_noalloc_dev(self, rays_ptr, n, hits_ptr):
+        check(lib().pt_trace_closest_noalloc_dev(self.h, C.c_void_p(rays_ptr), C.c_int(n), C.c_void_p(hits_ptr)))
 
     def counters(self):
         c = Counters()

@@ -201,6 +201,14 @@ int pt_trace_closest(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hits_out);
 int pt_trace_closest_dev(pt_ctx* ctx, const pt_ray* rays_dev, int n, pt_hit* hits_dev);
 int pt_trace_closest_fast(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hits_out);      /* same results through the traversal kernel the renderer uses (persistent waves, compact nodes) */
 int pt_trace_closest_fast_dev(pt_ctx* ctx, const pt_ray* rays_dev, int n, pt_hit* hits_dev);
+/* No counterpart in the reference. pt_trace_closest_fast_dev for callers that cannot allocate (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc): the same kernels and results, with
+ * every intermediate (packed rays, hits, block lists, counters) in a device block of about 12 MiB that is part
+ * of the library image on each GPU, so no allocating call is made. At most PT_NOALLOC_MAX_RAYS rays per call
+ * (larger n is PT_ERR_ARG). The block is shared by every context on a GPU and keeps the last call's contents:
+ * calls that overlap in time on one GPU (different streams or contexts) race; calls in stream order do not. */
+#define PT_NOALLOC_MAX_RAYS 262144
+int pt_trace_closest_noalloc_dev(pt_ctx* ctx, const pt_ray* rays_dev, int n, pt_hit* hits_dev);
 int pt_trace_closest_counted(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hits_out, uint32_t* box_tests_out, uint32_t* tri_tests_out);
 
 int pt_get_counters(pt_ctx* ctx, pt_counters* out);
