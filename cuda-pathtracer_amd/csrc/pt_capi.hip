@@ -1406,6 +1406,29 @@ int pt_detmath_probe(pt_ctx* c, const float* x, const float* y, int n, float* ou
     return PT_OK;
 }
 
+// BSDF probe: 12 outputs per item (see pt_kernels.hip)
+int pt_bsdf_probe(pt_ctx* c, const pt_material* mats, const int* inside, const float* V, const float* N, const float* L, const uint32_t* pixel, int frame, int n, float* out12)
+{
+    if (!c || !mats || !inside || !V || !N || !L || !pixel || !out12 || n <= 0) { set_error("pt_bsdf_probe: bad argument"); return PT_ERR_ARG; }
+    HIP_TRY(hipSetDevice(c->device));
+    DevBuf dm, di, dv, dn, dl, dp, dout;
+    HIP_TRY(dm.alloc((size_t)n * sizeof(pt_material))); HIP_TRY(di.alloc((size_t)n * 4)); HIP_TRY(dv.alloc((size_t)n * 12)); HIP_TRY(dn.alloc((size_t)n * 12));
+    HIP_TRY(dl.alloc((size_t)n * 12)); HIP_TRY(dp.alloc((size_t)n * 4)); HIP_TRY(dout.alloc((size_t)n * 48));
+    HIP_TRY(hipMemcpy(dm.p, mats, (size_t)n * sizeof(pt_material), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(di.p, inside, (size_t)n * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dv.p, V, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dn.p, N, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dl.p, L, (size_t)n * 12, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dp.p, pixel, (size_t)n * 4, hipMemcpyHostToDevice));
+    launch_bsdf_probe(dm.as<pt_material>(), di.as<int>(), dv.as<float>(), dn.as<float>(), dl.as<float>(), dp.as<uint32_t>(), frame, n, dout.as<float>(), c->stream);
+    hipError_t e = hipGetLastError();
+    hipError_t es = hipStreamSynchronize(c->stream);        // nothing may still use the buffers when they are freed
+    HIP_TRY(e);
+    HIP_TRY(es);
+    HIP_TRY(hipMemcpy(out12, dout.p, (size_t)n * 48, hipMemcpyDeviceToHost));
+    return PT_OK;
+}
+
 // ---------------------------------------------------------------- host-side producers
 struct pt_host_scene { HostScene s; };
 

@@ -306,6 +306,47 @@ __global__ void detmath_probe_kernel(const float* __restrict__ x, const float* _
     o[5] = pt_powf(a, b); o[6] = pt_acosf(a); o[7] = pt_atan2f(a, b);
     o[8] = 1.0f / a; o[9] = __builtin_sqrtf(a); o[10] = a / b; o[11] = (float)pt_dm_pow((double)a, (double)b);
 }
+// Device evaluation of the BSDF alone, for lobe-by-lobe comparison with the CPU restatement: item i evaluates
+// DisneyEval_2 (disney.cuh:234-347) for (V, N, L) and DisneySample_2 (disney.cuh:348-460) for (V, N) with the
+// random stream of (pixel[i], frame), on material record i. 12 floats per item: eval f.xyz, eval pdf, sampled
+// L.xyz, its f.xyz, its pdf, inside flag after the sample.
+__global__ __launch_bounds__(64) void bsdf_probe_kernel(const pt_material* __restrict__ mats, const int* __restrict__ inside, const float* __restrict__ V3,
+                                                         const float* __restrict__ N3, const float* __restrict__ L3, const uint32_t* __restrict__ pixel,
+                                                         int frame, int n, float* __restrict__ out)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const pt_material& M = mats[i];
+    Mat m;
+    m.base = ld3(M.baseColor); m.emis = ld3(M.emissive);
+    m.rough = pt_fmaxf(M.roughness, 0.0001f);            // pathtracer.cu:427
+    m.aniso = M.anisotropic; m.metal = M.metallic; m.subsurf = M.subsurface; m.sheen = M.sheen; m.coat = M.clearcoat;
+    m.coat_rough = M.clearcoatRoughness; m.strans = M.specTrans; m.alpha = M.alpha; m.ior = M.ior;
+    m.G = M.medium.G; m.sigA = ld3(M.medium.sigmaA); m.sigS = ld3(M.medium.sigmaS);
+    const bool in = inside[i] != 0;
+    const F3 V = ld3(V3 + 3 * (size_t)i), N = ld3(N3 + 3 * (size_t)i), L = ld3(L3 + 3 * (size_t)i);
+    float* o = out + (size_t)i * 12;
+    float pdf;
+    F3 f = disney::eval(m, in, V, N, L, pdf);
+    o[0] = f.x; o[1] = f.y; o[2] = f.z; o[3] = pdf;
+    Rng rng;
+    rng_seed(rng, pixel[i], (uint32_t)frame, 0);
+    bool in2 = in;
+    F3 Ls;
+    if (disney::sample_dir(m, in, V, N, Ls, rng, in2)) { f = f3(1.f, 1.f, 1.f); pdf = 1.f; }
+    else {
+        F3 T, B;
+        onb(N, T, B);
+        F3 Vrt = to_world(T, B, N, to_local(T, B, N, V));       // the local-frame round trip of disney.cuh:365,457
+        f = disney::eval(m, in, Vrt, N, Ls, pdf);
+    }
+    o[4] = Ls.x; o[5] = Ls.y; o[6] = Ls.z; o[7] = f.x; o[8] = f.y; o[9] = f.z; o[10] = pdf; o[11] = in2 ? 1.f : 0.f;
+}
+void launch_bsdf_probe(const pt_material* mats_dev, const int* inside_dev, const float* V_dev, const float* N_dev, const float* L_dev, const uint32_t* pixel_dev,
+                       int frame, int n, float* out_dev, hipStream_t stream)
+{
+    hipLaunchKernelGGL(bsdf_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, mats_dev, inside_dev, V_dev, N_dev, L_dev, pixel_dev, frame, n, out_dev);
+}
 __global__ void unorm8_probe_kernel(float* __restrict__ out) { out[threadIdx.x] = unorm8(threadIdx.x); }
 void launch_unorm8_probe(float* out_dev, hipStream_t stream) { hipLaunchKernelGGL(unorm8_probe_kernel, dim3(1), dim3(256), 0, stream, out_dev); }
 void launch_detmath_probe(const float* x_dev, const float* y_dev, int n, float* out_dev, hipStream_t stream)

@@ -24,6 +24,8 @@ int gpu_build_lbvh(const pt_triangle* tris_dev, int n, pt_bvh_node* nodes_dev, i
 void launch_env_tables(const float* cdf_dev, int w, int h, float* row_table_dev, float* col_table_dev, hipStream_t stream);
 void launch_env_texel_guide(const DScene& S, uint2* guide_dev, uint32_t* mismatches_dev, hipStream_t stream);
 void launch_env_guides(const DScene& S, uint32_t* row_guide_dev, uint32_t* col_guide_dev, uint32_t* mismatches_dev, hipStream_t stream);
+void launch_bsdf_probe(const pt_material* mats_dev, const int* inside_dev, const float* V_dev, const float* N_dev, const float* L_dev, const uint32_t* pixel_dev,
+                       int frame, int n, float* out_dev, hipStream_t stream);
 void launch_unorm8_probe(float* out_dev, hipStream_t stream);
 void launch_detmath_probe(const float* x_dev, const float* y_dev, int n, float* out_dev, hipStream_t stream);
 }

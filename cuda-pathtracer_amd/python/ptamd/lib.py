@@ -24,7 +24,7 @@ EXPORTS = [
     'pt_set_sky_mode', 'pt_set_env_guides', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_set_repack', 'pt_wavefront_stats', 'pt_set_lanes', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
     'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_save_exr', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
     'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_trace_closest_noalloc_dev', 'pt_debug_words', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
-    'pt_detmath_probe', 'pt_unorm8_probe', 'pt_set_texture_packing', 'pt_read_obj', 'pt_read_obj_general', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
+    'pt_detmath_probe', 'pt_bsdf_probe', 'pt_unorm8_probe', 'pt_set_texture_packing', 'pt_read_obj', 'pt_read_obj_general', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
     'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
     'pt_host_build_bvh', 'pt_load_hdr', 'pt_load_texture_png', 'pt_load_texture_image', 'pt_build_env_cdf', 'pt_free', 'pt_camera_basis',
 ]
@@ -379,6 +379,17 @@ class Renderer:
         out = np.zeros(256, dtype=np.float32)
         check(lib().pt_unorm8_probe(self.h, _p(out)))
         return out
+
+    def bsdf_probe(self, mats, inside, V, N, L, pixel, frame):
+        """Device DisneyEval_2 / DisneySample_2 per item: (eval_f[n,3], eval_pdf[n], L[n,3], f[n,3], pdf[n], inside_after[n])."""
+        mats = np.ascontiguousarray(mats, dtype=MAT_DTYPE)
+        n = len(mats)
+        inside = np.ascontiguousarray(inside, dtype=np.int32)
+        V, N, L = (np.ascontiguousarray(a, dtype=np.float32).reshape(n, 3) for a in (V, N, L))
+        pixel = np.ascontiguousarray(pixel, dtype=np.uint32)
+        out = np.zeros((n, 12), dtype=np.float32)
+        check(lib().pt_bsdf_probe(self.h, _p(mats), _p(inside), _p(V), _p(N), _p(L), _p(pixel), C.c_int(frame), C.c_int(n), _p(out)))
+        return out[:, 0:3], out[:, 3], out[:, 4:7], out[:, 7:10], out[:, 10], out[:, 11] != 0
 
     def detmath_probe(self, x, y):
         x = np.ascontiguousarray(x, dtype=np.float32)

@@ -218,6 +218,7 @@ int pt_stage_timing(pt_ctx* ctx, int on, double* extend_ms_out, uint64_t* extend
 int pt_debug_words(pt_ctx* ctx, unsigned long long* out16);                 /* diagnostic builds only: 16 statistics words of the traversal kernel, zeroed on read (all zero in a regular build) */
 int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* tri_bytes); /* size of the flattened BVH in HBM */
 int pt_detmath_probe(pt_ctx* ctx, const float* x, const float* y, int n, float* out12); /* device evaluation of include/pt_detmath.h, 12 results per input pair */
+int pt_bsdf_probe(pt_ctx* ctx, const pt_material* mats, const int* inside, const float* V3, const float* N3, const float* L3, const uint32_t* pixel, int frame, int n, float* out12); /* device evaluation of the BSDF alone, item i on material record i: DisneyEval_2 (disney.cuh:234-347) for (V, N, L) -> f.xyz, pdf; DisneySample_2 (disney.cuh:348-460) for (V, N) with the random stream of (pixel[i], frame) -> L.xyz, f.xyz, pdf, inside flag afterwards */
 int pt_unorm8_probe(pt_ctx* ctx, float* out256);                         /* device evaluation of the byte -> float conversion of packed textures */
 
 /* ---- host-side producers (no GPU needed) ---- */

@@ -1149,7 +1149,8 @@ void orc_build_cdf(const float* rgba, int w, int h, float* cdf, float* sum)
 void orc_closest_brute(const orc_scene* s, const pt_ray* rays, int n, orc_hit* out)
 {
     Scene S = view(s);
-#pragma omp parallel for schedule(dynamic, 64)
+    // one ray costs a pass over every triangle: small units, so a few hundred rays still use every core
+#pragma omp parallel for schedule(dynamic, 2)
     for (int i = 0; i < n; i++) {
         HitRec h = closest_brute(S, from(rays[i].o), from(rays[i].d));
         out[i] = orc_hit{h.t, h.tri, h.u, h.v};
