@@ -3,11 +3,15 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-Workload: the Sponza-class atrium (about 262k triangles, 25 PBR materials
+Workload (default): the Sponza-class atrium (about 262k triangles, 25 PBR materials
 with texture maps, 1024x512 HDR environment), 1920x1080, 64 samples per pixel per GPU per step, bounce
 cap 512 as in the reference.  One step = clear the accumulator, render this rank's 64 frames, sum the
 per-GPU accumulators on rank 0 (RCCL reduce, N > 1 only), resolve to RGBA8.  Ranks render disjoint
 frame ranges (sample partition), so work per GPU is fixed as N grows: weak scaling.
+--total-spp S fixes the samples per pixel of a step over all GPUs instead (rank r renders frames
+[r*S/N, (r+1)*S/N) of each step): strong scaling, the form of the 4096-spp and 1024-spp configurations.
+--workload soup renders the 10-million-triangle soup (tree built on the GPU), whose 2.4 GB of nodes and
+triangle records do not fit any cache: the case in which HBM bounds the traversal kernel.
 
 Prints one JSON line: metric Mrays/s (a ray is one closest-hit query: camera, bounce or shadow-walk
 segment), with samples/s, the roofline of the dominant kernel and the CPU oracle timed beside it.
@@ -45,6 +49,10 @@ def main():
     ap.add_argument('--spp', type=int, default=64, help='samples per pixel per GPU per step')
     ap.add_argument('--bounces', type=int, default=512)
     ap.add_argument('--detail', type=float, default=None, help='atrium tessellation (default: about 262k triangles)')
+    ap.add_argument('--workload', choices=['atrium', 'soup', 'sunsky'], default='atrium',
+                    help='atrium: the Sponza-class scene with its HDR environment; soup: 10 M random triangles; sunsky: the atrium with 30 %% glossy metal and 20 %% glass materials under the sun/sky model, bounce cap 16')
+    ap.add_argument('--soup-tris', type=int, default=10000000)
+    ap.add_argument('--total-spp', type=int, default=0, help='samples per pixel of one step over ALL GPUs (strong scaling); 0 = --spp per GPU (weak scaling)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU oracle baseline')
     ap.add_argument('--cpu-spp', type=int, default=12, help='frames the CPU oracle renders for the baseline (about 15 s on 16 cores)')
     ap.add_argument('--mode', choices=['wavefront', 'single_kernel'], default='wavefront')
@@ -58,6 +66,7 @@ def main():
     ap.add_argument('--lanes', type=int, default=0, help='concurrent wavefront lanes (0 = library default)')
     ap.add_argument('--drain', type=int, default=-1, help='finish the last paths in one kernel once at most this many remain (-1 = library default, 0 = never)')
     ap.add_argument('--node-width', type=int, default=4, help='4-wide or binary (2) compact nodes in the traversal kernel')
+    ap.add_argument('--leaf-merge', type=int, default=2, help='triangles per wide leaf at most')
     ap.add_argument('--tune', type=str, default='', help='refill_lanes,leaf_vote,blocks_per_cu for the traversal kernel')
     args = ap.parse_args()
 
@@ -84,17 +93,50 @@ def main():
             dist.init_process_group(args.backend)
 
     W, H, spp = args.width, args.height, args.spp
+    strong = args.total_spp > 0
+    if strong and args.total_spp < world:
+        raise SystemExit('--total-spp must be at least the number of GPUs')
     detail = args.detail if args.detail is not None else util.ATRIUM_DETAIL
     # every rank generates the same seeded scene in its own directory
     util.SCRATCH = os.path.join(ROOT, 'tests', '_scratch', 'rank%d' % rank)
-    bundle = util.atrium(detail=detail)
-    P = scenes.atrium_params(ptamd.default_params(W, H))
-    r = bundle.renderer(P, device, pack_textures=not args.fp32_textures)
+    bundle = None
+    if args.workload == 'soup':
+        from ptamd import lib as ptlib
+        tris, mats = scenes.soup(args.soup_tris, seed=2, extent=5000.0, edge=5.0)
+        env = scenes.sky_envmap(256, 128)
+        env4 = np.concatenate([env, np.zeros(env.shape[:2] + (1,), np.float32)], -1)
+        cdf, env_total = ptlib.build_env_cdf(env4)
+        P = ptamd.default_params(W, H)
+        P.rayOrigin = ptamd.Float3(0.0, 0.0, 9000.0)
+        P.isRendering = 1
+        r = ptamd.Renderer(device)
+        r.init(P)
+        r.upload_scene(tris, mats, None, None, flavour=ptlib.PT_BVH_GPU_LBVH)
+        r.upload_envmap(env4, cdf, env_total, P)
+        n_tris = len(tris)
+        workload_name = 'soup of %d random triangles (tree built on the GPU), 256x128 HDR envmap' % n_tris
+    else:
+        if args.workload == 'sunsky':
+            bundle = util.atrium(detail=detail, glossy=0.3, glass=0.2, sky_mode=1)
+            if args.bounces == 512:
+                args.bounces = 16
+        else:
+            bundle = util.atrium(detail=detail)
+        P = scenes.atrium_params(ptamd.default_params(W, H))
+        r = bundle.renderer(P, device, pack_textures=not args.fp32_textures)
+        n_tris = len(bundle.tris)
+        workload_name = 'atrium (Sponza-class, %d triangles, 25 PBR materials, %s)' % (
+            n_tris, '1024x512 HDR envmap' if args.workload == 'atrium' else '30 % glossy metal and 20 % glass materials, sun/sky model')
     r.set_max_bounces(args.bounces)
     r.set_mode(0 if args.mode == 'wavefront' else 1)
     if args.pool or args.chunk_frames:
         r.set_pool(args.pool or (1 << 24), args.chunk_frames or 512)
-    r.set_node_width(args.node_width)
+    if args.node_width != 4 or args.leaf_merge != 2:
+        r.set_node_width(args.node_width, args.leaf_merge)
+        if bundle is not None:
+            r.upload_scene(bundle.tris, bundle.mats, bundle.idx, bundle.nodes)
+        else:
+            r.upload_scene(tris, mats, None, None, flavour=ptlib.PT_BVH_GPU_LBVH)
     if args.drain >= 0:
         r.set_drain(args.drain)
     if args.lanes:
@@ -122,13 +164,22 @@ def main():
 
     kernel_ms = []
 
+    def frames_of(k):
+        """Frame range this rank renders in step k."""
+        if strong:
+            a, b = ptamd.partition.split_frames(args.total_spp, world, rank)
+            return k * args.total_spp + a, k * args.total_spp + b
+        return ptamd.partition.step_frames(k, world, rank, spp)
+
+    step_spp = args.total_spp if strong else spp * world       # samples per pixel one step adds over all GPUs
+
     def step(k, timed):
-        f0, f1 = ptamd.partition.step_frames(k, world, rank, spp)
+        f0, f1 = frames_of(k)
         accum.zero_()
         r.render(P, f0, f1, sync=False)
         ptamd.partition.reduce_accum(accum, dst=0)
         if rank == 0:
-            r.resolve_display(spp * world)
+            r.resolve_display(step_spp)
         else:
             torch.cuda.synchronize()
         if timed:
@@ -150,15 +201,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # untimed: count rays and tests of exactly the timed frames with the instrumented kernels
-    r.enable_counters(True)
-    r.reset_counters()
-    for k in range(args.steps):
-        f0, f1 = ptamd.partition.step_frames(args.warmup + k, world, rank, spp)
-        r.render(P, f0, f1)
-    c = r.counters()
+    # untimed: count rays and tests of exactly the timed frames with the instrumented kernels, twice: the
+    # reference-order binary walk (its box and triangle tests are the reference's own) and the production walk
+    # over the wide nodes (the node visits and triangle tests the timed kernel really made)
+    c = {}
+    for mode in (1, 2):
+        r.enable_counters(mode)
+        r.reset_counters()
+        for k in range(args.steps):
+            f0, f1 = frames_of(args.warmup + k)
+            r.render(P, f0, f1)
+        got = r.counters()
+        if mode == 1:
+            c.update(got)
+        else:
+            c['wide_nodes'], c['wide_tris'] = got['wide_nodes'], got['wide_tris']
     r.enable_counters(False)
-    keys = ['rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps', 'tex_taps_r']
+    keys = ['rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps', 'tex_taps_r', 'wide_nodes', 'wide_tris']
     local = torch.tensor([float(c[k]) for k in keys], dtype=torch.float64, device='cuda')
     total = local.clone()
     if world > 1:
@@ -172,47 +231,69 @@ def main():
         if args.mode == 'wavefront':
             # dominant kernel: extend (closest hit for every pending ray of the pool), one launch per iteration
             kname = 'wf_extend_kernel'
-            kms = extend_ms / max(extend_launches, 1)
-            alg_per_launch = (40 * loc['rays'] + 32 * loc['box_tests'] + 48 * loc['tri_tests']) / max(extend_launches, 1)
+            launches = max(extend_launches, 1)
+            kms = extend_ms / launches
+            # bytes the timed kernel's own walk asks the memory system for: per ray 32 in + 16 out (the slot
+            # arrays), 64 per wide node visited, 48 per triangle tested
+            own_per_launch = (48 * loc['rays'] + 64 * loc['wide_nodes'] + 48 * loc['wide_tris']) / launches
+            # the layout-independent accounting on the reference's binary walk
+            ref_per_launch = (40 * loc['rays'] + 32 * loc['box_tests'] + 48 * loc['tri_tests']) / launches
+            alg_per_launch = own_per_launch if loc['wide_nodes'] > 0 else ref_per_launch
         else:
             kname = 'render_samples_kernel'
+            launches = args.steps
             kms = float(np.mean(kernel_ms))
-            alg_per_launch = algorithmic_bytes(loc) / args.steps
+            alg_per_launch = ref_per_launch = own_per_launch = algorithmic_bytes(loc) / args.steps
         achieved = alg_per_launch / (kms * 1e-3) / 1e9
         node_b, tri_b = r.scene_bytes()
         traffic = None
-        valu = {}
+        issue = None
         pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
         if os.path.exists(pmc_path):
             try:
                 with open(pmc_path) as f:
-                    pm = json.load(f)
+                    pm = json.load(f).get(args.workload, {})
                 if pm.get('workload') == [W, H, spp, args.bounces]:
                     traffic = pm.get('hbm_bytes_per_launch')
-                    valu = {k: pm[k] for k in ('valu_busy', 'valu_lanes_per_instruction', 'valu_note') if k in pm}
+                    issue = pm.get('issue')
             except Exception:
                 traffic = None
         result = {
             'metric': 'Mrays/s', 'value': round(mrays, 3), 'unit': 'Mrays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 3),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'samples_per_s': round(tot['samples'] / elapsed, 1),
             'rays_per_sample': round(tot['rays'] / tot['samples'], 3),
-            'config': {'workload': 'atrium (Sponza-class, %d triangles, 25 PBR materials, 1024x512 HDR envmap) %dx%d, %d spp per GPU per step, bounce cap %d'
-                                   % (len(bundle.tris), W, H, spp, args.bounces),
-                       'partition': 'samples: rank r renders frames [(k*N+r)*spp, +spp), RCCL reduce to rank 0' if world > 1 else 'single GPU',
+            'config': {'workload': '%s %dx%d, %s, bounce cap %d'
+                                   % (workload_name, W, H, ('%d spp per step over all GPUs' % args.total_spp) if strong else ('%d spp per GPU per step' % spp), args.bounces),
+                       'partition': ('single GPU' if world == 1 else
+                                     ('samples: rank r renders frames [k*S + r*S/N, k*S + (r+1)*S/N) of step k, RCCL reduce to rank 0' if strong else
+                                      'samples: rank r renders frames [(k*N+r)*spp, +spp), RCCL reduce to rank 0')),
                        'scene_bytes': {'nodes': node_b, 'triangles': tri_b}},
-            'roofline': {'bound': 'hbm', 'kernel': kname, 'launches': int(extend_launches) if args.mode == 'wavefront' else args.steps, 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
+            'roofline': {'bound': 'hbm', 'kernel': kname, 'launches': int(launches), 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
                          'kernel_ms': round(kms, 4),
-                         'note': 'algorithmic bytes = 40 per ray + 32 per box test + 48 per triangle test of the reference-order traversal (counted); the scene is cache resident and the kernel walks 4-wide nodes, so fewer bytes reach HBM (traffic) and frac can exceed 1',
-                         'whole_path_algorithmic_GBs': round(algorithmic_bytes(loc) / (elapsed * 1e9), 2), 'algorithmic_bytes_per_launch': int(alg_per_launch), **valu},
+                         'algorithmic_bytes_per_launch': int(alg_per_launch),
+                         'own_walk_per_ray': {'wide_nodes': round(loc['wide_nodes'] / max(loc['rays'], 1), 3), 'tri_tests': round(loc['wide_tris'] / max(loc['rays'], 1), 3),
+                                              'bytes': round(own_per_launch * launches / max(loc['rays'], 1), 1)},
+                         'reference_walk': {'box_tests_per_ray': round(loc['box_tests'] / max(loc['rays'], 1), 3), 'tri_tests_per_ray': round(loc['tri_tests'] / max(loc['rays'], 1), 3),
+                                            'bytes_per_launch': int(ref_per_launch), 'achieved': round(ref_per_launch / (kms * 1e-3) / 1e9, 2),
+                                            'frac': round(ref_per_launch / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                         'hbm_traffic_frac': (round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
+                         'issue': issue,
+                         'note': ('achieved = bytes the timed kernel asks the memory system for (48 per ray in the slot arrays + 64 per wide node it visits + 48 per triangle it tests, '
+                                  'counted on the production walk) / its mean launch time; reference_walk = the same with the layout-independent accounting on the reference\'s binary walk '
+                                  '(40 + 32 per box test + 48 per triangle test). '
+                                  + ('The 30 MB scene is served from L2 / Infinity Cache, so this fraction measures cache gather rate against the HBM peak, not HBM use: traffic (PMC) is what reaches memory, '
+                                     'and the kernel is bound by vector instruction issue (issue).' if args.workload != 'soup' else
+                                     'The 2.4 GB scene fits no cache: the node and triangle reads are random 64-byte HBM accesses.')),
+                         'whole_path_algorithmic_GBs': round(algorithmic_bytes(loc) / (elapsed * 1e9), 2)},
         }
 
     # CPU baseline: the oracle on this host's cores, rank 0, single-GPU runs only, bounded sample
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and bundle is not None:
         import orc
         S = bundle.oracle(P)
         cpu_spp = args.cpu_spp

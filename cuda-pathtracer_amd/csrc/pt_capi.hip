@@ -72,7 +72,7 @@ struct pt_ctx {
     DScene scene{};
     bool have_tris = false, have_bvh = false, have_mats = false, have_env = false;
     int max_bounces = 512;
-    bool counting = false;
+    int counting = 0;               // 0 off, 1 the reference-order walk, 2 the production walk's own work
     DCounters* d_ctr = nullptr;
     pt_counters totals{};
     size_t n_nodes = 0;
@@ -705,7 +705,8 @@ int pt_enable_counters(pt_ctx* c, int on)
 {
     if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
     if (!c) { set_error("null context"); return PT_ERR_ARG; }
-    c->counting = on != 0;
+    if (on < 0 || on > 2) { set_error("pt_enable_counters: 0, 1 or 2"); return PT_ERR_ARG; }
+    c->counting = on;
     return PT_OK;
 }
 
@@ -760,7 +761,10 @@ static int fetch_counters(pt_ctx* c)
     DCounters h;
     HIP_TRY(hipMemcpyAsync(&h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->totals.rays += h.rays; c->totals.samples += h.samples; c->totals.box_tests += h.box_tests; c->totals.tri_tests += h.tri_tests;
+    c->totals.rays += h.rays; c->totals.samples += h.samples;
+    const bool wide_walk = c->counting == 2 && c->scene.wide && c->mode == PT_MODE_WAVEFRONT;
+    if (wide_walk) { c->totals.wide_nodes += h.box_tests; c->totals.wide_tris += h.tri_tests; }
+    else { c->totals.box_tests += h.box_tests; c->totals.tri_tests += h.tri_tests; }
     c->totals.shade_vertices += h.shade_vertices; c->totals.env_samples += h.env_samples; c->totals.tex_taps += h.tex_taps; c->totals.tex_taps_r += h.tex_taps_r;
     HIP_TRY(hipMemsetAsync(c->d_ctr, 0, sizeof(DCounters), c->stream));
     return PT_OK;
@@ -817,6 +821,7 @@ static int lane_pool(pt_ctx* c, pt_ctx::WfLane& L, size_t slots, WfParams* w)
     L.pool_side = 0;
     pool_layout(c, L, L.block, slots, w);
     w->refill_lanes = c->refill_lanes; w->leaf_vote = c->leaf_vote;
+    w->count_wide = c->counting == 2 ? 1 : 0;
     w->extend_blocks = (c->extend_blocks_per_cu ? c->extend_blocks_per_cu : 5) * c->n_cus;
     return PT_OK;
 }

@@ -364,8 +364,8 @@ PT_DEV float wide_ray(const DScene& S, F3 o, F3 d, F3& invq, F3& noq)
 // closest_hit over the 4-wide quantized nodes, one ray per lane from start to end (the persistent traversal
 // kernel of the stage pipeline shares wide_step but regroups its lanes between passes). The visiting order is
 // not the reference's; the closest hit and its tie rule do not depend on it.
-template <int BLOCK, int LDS_DEPTH>
-PT_DEV Hit closest_hit_wide(const DScene& S, F3 o, F3 d, int tid)
+template <int BLOCK, int LDS_DEPTH, bool COUNT = false>
+PT_DEV Hit closest_hit_wide(const DScene& S, F3 o, F3 d, int tid, uint32_t& nnode, uint32_t& ntri)
 {
     __shared__ uint2 s_stack[LDS_DEPTH * BLOCK];
     uint2 spill[kSpillDepth];
@@ -400,6 +400,7 @@ PT_DEV Hit closest_hit_wide(const DScene& S, F3 o, F3 d, int tid)
             const float4* np = reinterpret_cast<const float4*>(S.nodes4 + cur);
             float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             int r0, r1, r2, r3; float d0, d1, d2, d3;
+            if (COUNT) nnode += 1;
             wide_step(n0, n1, n2, n3, invq, noq, best.t, r0, r1, r2, r3, d0, d1, d2, d3);
             if (d3 < 1e30f) push(r3, d3);
             if (d2 < 1e30f) push(r2, d2);
@@ -415,6 +416,7 @@ PT_DEV Hit closest_hit_wide(const DScene& S, F3 o, F3 d, int tid)
                 float4 q0 = tp[i].q0, q1 = tp[i].q1, q2 = tp[i].q2;
                 uint32_t id = __float_as_uint(q0.w);
                 float t, u, v;
+                if (COUNT) ntri += 1;
                 if (!tri_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), o, d, best.t, t, u, v)) continue;
                 if (best.tri != PT_NO_TRI && t == best.t && id > best.tri) continue;
                 best.t = t; best.tri = id; best.u = u; best.v = v;

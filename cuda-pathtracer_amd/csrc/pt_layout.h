@@ -142,6 +142,7 @@ struct WfParams {
     int px_lane, px_lanes;
     uint32_t n_pixels;
     int refill_lanes, leaf_vote, extend_blocks;   // extend-kernel tuning (see wf_extend_kernel)
+    int count_wide;                               // counting builds: tally the production (wide) walk's own work instead of the reference-order walk
 };
 
 } // namespace ptamd

@@ -311,6 +311,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
 //   COUNT: walks the 64-byte fp32 binary nodes in the reference's order and tallies box and triangle
 //          tests, which then equal the oracle's counts.
 //   WIDE:  walks the 4-wide quantized nodes (closest hits do not depend on the visiting order).
+//   both:  the 4-wide walk with its own work tallied: wide nodes visited (in the box counter) and triangle tests.
 //   neither: the binary quantized nodes, for trees too deep for the 4-wide stack.
 #ifndef PT_SKIP_ROOT_TEST
 #define PT_SKIP_ROOT_TEST 1
@@ -336,8 +337,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     F3 o = f3(0.f, 0.f, 0.f), d = o, inv = o;
     // ray in grid coordinates for the compact nodes (uncounted build only)
     F3 oq = o, invq = o, noq = o;
-    static_assert(!(COUNT && WIDE), "the counting build walks the binary tree the reference walks");
-    constexpr bool QUANT = !COUNT;
+    constexpr bool QUANT = WIDE || !COUNT;
     Hit best; best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
     bool has_ray = false;
     bool more = true;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     const uint32_t n_small = n_chunks < PT_TAIL_FACTOR * gridDim.x ? n_chunks : PT_TAIL_FACTOR * gridDim.x, n_big = n_chunks - n_small;
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
 #if PT_STAMPS
-    unsigned long long st_iters = 0, st_lanes = 0, st_leafphases = 0, st_refills = 0, st_leaflanes = 0, st_idle = 0, st_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long st_iters = 0, st_lanes = 0, st_leafphases = 0, st_refills = 0, st_leaflanes = 0, st_idle = 0, st_tail = 0, st_tail_idle = 0, st_tail_desc = 0, st_tail_t0 = 0, st_t0 = __builtin_amdgcn_s_memtime();
 #endif
 
     auto push = [&](int ref, float tn) {
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
 #if PT_STAMPS
         st_iters++; st_lanes += __popcll(desc_mask); st_leafphases += __any(leaf_now) ? 1 : 0; st_refills += do_refill ? 1 : 0;
         st_leaflanes += __popcll(__ballot(leaf_now)); st_idle += n_idle;
+        if (!more) { if (!st_tail) st_tail_t0 = __builtin_amdgcn_s_memtime(); st_tail++; st_tail_idle += n_idle; st_tail_desc += __popcll(desc_mask); }
 #endif
         // ---- issue every load of the pass before anything waits: a pass then costs one memory latency,
         // not one per kind of work
@@ -454,6 +455,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                                      __float_as_uint(n1.x), __float_as_uint(n1.y), __float_as_uint(n1.z), __float_as_uint(n1.w),
                                      __float_as_uint(n2.x), __float_as_uint(n2.y), __float_as_uint(n2.z), __float_as_uint(n2.w)};
             int r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y), r2 = __float_as_int(n3.z), r3 = __float_as_int(n3.w);
+            if (COUNT) tl.box += 1;
             float dk[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -551,7 +553,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                 // last-bit error cannot lose a box, and saves three IEEE divisions per ray
                 if (QUANT) inv = f3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
                 else inv = 1.0f / d;
-                if (COUNT) tl.box += 1;
+                if (COUNT && !WIDE) tl.box += 1;
 #if PT_SKIP_ROOT_TEST
                 // the 4-wide walk starts at the root node without testing the scene box: the root's child boxes cull
                 // a ray that misses the scene in one step, and nearly every ray of a render starts inside it
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     if (lane == 0 && n_chunks * 10u >= (uint32_t)(w.n_slots / kRayChunk) * 9u) {      // full launches only
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(w.counters + WF_CTR_WORDS);
         atomicAdd(dbg + 0, __builtin_amdgcn_s_memtime() - st_t0); atomicAdd(dbg + 1, st_refills); atomicAdd(dbg + 3, st_iters);
-        atomicAdd(dbg + 4, st_lanes); atomicAdd(dbg + 5, st_leafphases); atomicAdd(dbg + 6, 1ull); atomicAdd(dbg + 7, st_leaflanes); atomicAdd(dbg + 8, st_idle);
+        atomicAdd(dbg + 4, st_lanes); atomicAdd(dbg + 5, st_leafphases); atomicAdd(dbg + 6, 1ull); atomicAdd(dbg + 7, st_leaflanes); atomicAdd(dbg + 8, st_idle); atomicAdd(dbg + 9, st_tail); atomicAdd(dbg + 10, st_tail_idle); atomicAdd(dbg + 11, st_tail_desc); atomicAdd(dbg + 12, st_tail ? __builtin_amdgcn_s_memtime() - st_tail_t0 : 0ull);
     }
 #endif
     flush_tally<COUNT>(ctr, tl, 0);
@@ -785,7 +787,7 @@ __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, 
             F3 ro = shadow ? P.so : P.o;
             F3 rd = shadow ? P.sd : P.d;
             Hit h;
-            if (WIDE) h = closest_hit_wide<kBlock, kLdsDepth>(S, ro, rd, threadIdx.x);
+            if (WIDE) h = closest_hit_wide<kBlock, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
             else h = closest_hit<kBlock, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
             if (COUNT) tl.rays++;
             Surf info;
@@ -998,7 +1000,8 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
     // persistent waves: enough workgroups to fill every CU, each pulls rays until the pool is drained
     int ext_blocks = (w.n_slots + kBlock - 1) / kBlock;
     if (ext_blocks > w.extend_blocks) ext_blocks = w.extend_blocks;
-    if (ctr) hipLaunchKernelGGL((wf_extend_kernel<true, false>), dim3(ext_blocks), block, 0, s, w, S, ctr);
+    if (ctr && w.count_wide && S.wide) hipLaunchKernelGGL((wf_extend_kernel<true, true>), dim3(ext_blocks), block, 0, s, w, S, ctr);
+    else if (ctr) hipLaunchKernelGGL((wf_extend_kernel<true, false>), dim3(ext_blocks), block, 0, s, w, S, ctr);
     else if (S.wide) hipLaunchKernelGGL((wf_extend_kernel<false, true>), dim3(ext_blocks), block, 0, s, w, S, ctr);
     else hipLaunchKernelGGL((wf_extend_kernel<false, false>), dim3(ext_blocks), block, 0, s, w, S, ctr);
     if (ext1) (void)hipEventRecord(ext1, s);
@@ -1062,7 +1065,8 @@ void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int
     int max_blocks = (max_paths + kBlock - 1) / kBlock;
     if (max_blocks > n_blocks) max_blocks = n_blocks;
     if (max_blocks < 1) max_blocks = 1;
-    if (ctr) hipLaunchKernelGGL((wf_drain_kernel<true, false>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
+    if (ctr && w.count_wide && S.wide) hipLaunchKernelGGL((wf_drain_kernel<true, true>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
+    else if (ctr) hipLaunchKernelGGL((wf_drain_kernel<true, false>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
     else if (S.wide) hipLaunchKernelGGL((wf_drain_kernel<false, true>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
     else hipLaunchKernelGGL((wf_drain_kernel<false, false>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
 }

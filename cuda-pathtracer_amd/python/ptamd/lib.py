@@ -276,7 +276,8 @@ class Renderer:
         check(lib().pt_set_max_bounces(self.h, C.c_int(n)))
 
     def enable_counters(self, on=True):
-        check(lib().pt_enable_counters(self.h, C.c_int(1 if on else 0)))
+        """False/0 off, True/1 count the reference-order walk, 2 count the production walk over the wide nodes."""
+        check(lib().pt_enable_counters(self.h, C.c_int(int(on))))
 
     def clear_accum(self):
         check(lib().pt_clear_accum(self.h))

@@ -132,6 +132,8 @@ typedef struct pt_counters {
     uint64_t env_samples;   /* envmap importance samples drawn */
     uint64_t tex_taps;      /* bilinear lookups into 4-channel textures (materials, environment radiance) */
     uint64_t tex_taps_r;    /* bilinear lookups into 1-channel textures (roughness/metallic/emissive maps, environment CDF) */
+    uint64_t wide_nodes;    /* pt_enable_counters(ctx, 2) only: wide nodes the production traversal visited (box_tests and tri_tests stay 0 then) */
+    uint64_t wide_tris;     /* pt_enable_counters(ctx, 2) only: triangle tests of the production traversal */
     double   last_ms;       /* device time of the last render / trace call (HIP events) */
 } pt_counters;
 
@@ -213,7 +215,7 @@ int pt_trace_closest_counted(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hit
 
 int pt_get_counters(pt_ctx* ctx, pt_counters* out);
 int pt_reset_counters(pt_ctx* ctx);
-int pt_enable_counters(pt_ctx* ctx, int on);                            /* instrumented kernels (slower); off by default */
+int pt_enable_counters(pt_ctx* ctx, int on);                            /* instrumented kernels (slower); off by default. 1: the reference-order binary walk is traced and its box and triangle tests counted (equal to the reference's counts, pathtracer.cu:207,230); 2: the production walk over the wide nodes is traced and its own node visits and triangle tests counted (wide_nodes, wide_tris) */
 int pt_stage_timing(pt_ctx* ctx, int on, double* extend_ms_out, uint64_t* extend_launches_out); /* HIP-event time of the extend kernel: returns the totals since the last call, then switches timing on/off and clears them */
 int pt_debug_words(pt_ctx* ctx, unsigned long long* out16);                 /* diagnostic builds only: 16 statistics words of the traversal kernel, zeroed on read (all zero in a regular build) */
 int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* tri_bytes); /* size of the flattened BVH in HBM */

@@ -93,6 +93,14 @@ int main(int argc, char** argv)
     run("2 x 16B of a 64B record", [&] { hipLaunchKernelGGL((chase<2, 4>), dim3(blocks), dim3(256), 0, 0, d, nrec, iters, out); }, 1);
     run("4 x 16B of a 64B record", [&] { hipLaunchKernelGGL((chase<4, 4>), dim3(blocks), dim3(256), 0, 0, d, nrec, iters, out); }, 1);
     run("2 x 16B of a 32B record", [&] { hipLaunchKernelGGL((chase<2, 2>), dim3(blocks), dim3(256), 0, 0, d, nrec * 2, iters, out); }, 1);
+    // other record sizes: n16 = number of 16-byte units in the buffer
+    const uint32_t n16 = nrec * 4;
+    run("3 x 16B of a 48B record", [&] { hipLaunchKernelGGL((chase<3, 3>), dim3(blocks), dim3(256), 0, 0, d, n16 / 3, iters, out); }, 1);
+    run("5 x 16B of an 80B record", [&] { hipLaunchKernelGGL((chase<5, 5>), dim3(blocks), dim3(256), 0, 0, d, n16 / 5, iters, out); }, 1);
+    run("5 x 16B in a 128B slot", [&] { hipLaunchKernelGGL((chase<5, 8>), dim3(blocks), dim3(256), 0, 0, d, n16 / 8, iters, out); }, 1);
+    run("6 x 16B of a 96B record", [&] { hipLaunchKernelGGL((chase<6, 6>), dim3(blocks), dim3(256), 0, 0, d, n16 / 6, iters, out); }, 1);
+    run("8 x 16B of a 128B record", [&] { hipLaunchKernelGGL((chase<8, 8>), dim3(blocks), dim3(256), 0, 0, d, n16 / 8, iters, out); }, 1);
+    run("4 x 16B in a 128B slot", [&] { hipLaunchKernelGGL((chase<4, 8>), dim3(blocks), dim3(256), 0, 0, d, n16 / 8, iters, out); }, 1);
     run("4x16B, 32 waves/CU, 64 ALU", [&] { hipLaunchKernelGGL((chase_model<16384, 64>), dim3(blocks), dim3(256), 0, 0, d, nrec, iters, out); }, 1);
     run("4x16B, 20 waves/CU, 64 ALU", [&] { hipLaunchKernelGGL((chase_model<32768, 64>), dim3(blocks), dim3(256), 0, 0, d, nrec, iters, out); }, 1);
     run("4x16B, 20 waves/CU, 160 ALU", [&] { hipLaunchKernelGGL((chase_model<32768, 160>), dim3(blocks), dim3(256), 0, 0, d, nrec, iters, out); }, 1);

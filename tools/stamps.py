@@ -19,3 +19,7 @@ total, refills, _, iters, lanes, leafph, waves, leaflanes, idle = [d[i] for i in
 print('waves %d  iterations/wave %.0f  cycles/iteration %.0f  descending lanes/iteration %.1f  leaf passes/iteration %.3f  refills/iteration %.3f'
       % (waves, iters / waves, total / iters, lanes / iters, leafph / iters, refills / iters))
 print('lanes in a leaf pass %.1f  idle lanes/iteration %.1f  lanes waiting at a leaf/iteration %.1f' % (leaflanes / max(leafph, 1), idle / iters, 64 - lanes / iters - idle / iters))
+tail, tail_idle, tail_desc = d[9], d[10], d[11]
+print('tail (no more blocks to take): %.1f %% of the iterations, idle lanes %.1f, descending %.1f; before the tail: idle %.1f, descending %.1f'
+      % (100.0 * tail / iters, tail_idle / max(tail, 1), tail_desc / max(tail, 1), (idle - tail_idle) / max(iters - tail, 1), (lanes - tail_desc) / max(iters - tail, 1)))
+print('time in the tail: %.1f %% of the wave cycles' % (100.0 * d[12] / total))
