@@ -450,6 +450,36 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
         if (sub_count[ref] <= leaf_merge && sub_count[ref] <= 16) return wide_leaf(sub_first[ref], sub_count[ref]);
         return ref;
     };
+    // Tight bounds of the triangles below each child of every binary node (the boxes the uploaded tree carries may
+    // be padded, as the reference builder's are by 0.1 per vertex, BVH_builder.cpp:19-24), and the safety margin the
+    // wide boxes get instead: 2^-19 of the largest coordinate, a few times the rounding of the box and triangle tests.
+    struct TightBox { float lo[3], hi[3]; };
+    std::vector<TightBox> tight_l(dn.size()), tight_r(dn.size());
+    double max_coord = 0.0;
+    {
+        auto leaf_bounds = [&](int ref) {
+            TightBox b; for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
+            const int first = ~ref, count = leaf_count(ref);
+            for (int j = first; j < first + count; j++) {
+                const pt_triangle& T = c->tris[__builtin_bit_cast(uint32_t, dt[(size_t)j].q0.w)];
+                const float* v[3] = {&T.a.x, &T.b.x, &T.c.x};
+                for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { b.lo[a] = std::fmin(b.lo[a], v[k][a]); b.hi[a] = std::fmax(b.hi[a], v[k][a]); }
+            }
+            return b;
+        };
+        auto join = [](const TightBox& x, const TightBox& y) { TightBox b; for (int a = 0; a < 3; a++) { b.lo[a] = std::fmin(x.lo[a], y.lo[a]); b.hi[a] = std::fmax(x.hi[a], y.hi[a]); } return b; };
+        if (c->scene.root_ref >= 0) {
+            for (int i = (int)dn.size() - 1; i >= 0; i--) {       // children have larger indices than their parents
+                tight_l[i] = dn[i].left < 0 ? leaf_bounds(dn[i].left) : join(tight_l[dn[i].left], tight_r[dn[i].left]);
+                tight_r[i] = dn[i].right < 0 ? leaf_bounds(dn[i].right) : join(tight_l[dn[i].right], tight_r[dn[i].right]);
+            }
+        }
+        for (const pt_triangle& T : c->tris) {
+            const float* v[3] = {&T.a.x, &T.b.x, &T.c.x};
+            for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { double m = std::fabs((double)v[k][a]); if (m > max_coord && m < 1e30) max_coord = m; }
+        }
+    }
+    const double margin = std::ldexp(max_coord > 0.0 ? max_coord : 1.0, -19);
     if (c->scene.root_ref >= 0 && wide_ref(0) >= 0) {
         struct Cand { int ref; const float* lo; const float* hi; };      // ref: wide leaf (< 0) or binary interior index
         struct Item { int src, dst, need; };
@@ -460,24 +490,43 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
         while (!st.empty()) {
             Item it = st.back(); st.pop_back();
             std::vector<Cand> cand;
-            cand.push_back(Cand{wide_ref(dn[it.src].left), dn[it.src].lmin, dn[it.src].lmax});
-            cand.push_back(Cand{wide_ref(dn[it.src].right), dn[it.src].rmin, dn[it.src].rmax});
+            cand.push_back(Cand{wide_ref(dn[it.src].left), tight_l[it.src].lo, tight_l[it.src].hi});
+            cand.push_back(Cand{wide_ref(dn[it.src].right), tight_r[it.src].lo, tight_r[it.src].hi});
             while (cand.size() < 4) {
                 int pick = -1; double best = -1.0;
                 for (size_t k = 0; k < cand.size(); k++) if (cand[k].ref >= 0 && area(cand[k]) > best) { best = area(cand[k]); pick = (int)k; }
                 if (pick < 0) break;
-                const DNode& s = dn[cand[pick].ref];
-                cand[pick] = Cand{wide_ref(s.left), s.lmin, s.lmax};
-                cand.push_back(Cand{wide_ref(s.right), s.rmin, s.rmax});
+                const int src = cand[pick].ref;
+                cand[pick] = Cand{wide_ref(dn[src].left), tight_l[src].lo, tight_l[src].hi};
+                cand.push_back(Cand{wide_ref(dn[src].right), tight_r[src].lo, tight_r[src].hi});
             }
             DNode4 d{};
             int need = it.need + (int)cand.size() - 1;
             if (need > stack_need_wide) stack_need_wide = need;
+            // the node's grid: origin at the lowest corner of the widened boxes (rounded down to single precision),
+            // cell = the smallest power of two with which the boxes span at most 255 cells
+            uint32_t exps = 0;
+            for (int a = 0; a < 3; a++) {
+                double lo = INFINITY, hi = -INFINITY;
+                for (const Cand& k : cand) { lo = std::fmin(lo, (double)k.lo[a] - margin); hi = std::fmax(hi, (double)k.hi[a] + margin); }
+                if (!(lo > -1e30 && hi < 1e30)) { wide_ok = false; lo = 0.0; hi = 1.0; }      // non-finite vertices: the binary walk takes the scene
+                float org = (float)lo;
+                if ((double)org > lo) org = std::nextafterf(org, -INFINITY);
+                int e = -126;
+                while (hi - (double)org > 255.0 * std::ldexp(1.0, e) && e < 127) e++;
+                const double cell = std::ldexp(1.0, e);
+                d.w[a] = __builtin_bit_cast(uint32_t, org);
+                exps |= (uint32_t)(uint8_t)(int8_t)e << (8 * a);
+                for (size_t k = 0; k < cand.size(); k++) {
+                    double ql = std::floor(((double)cand[k].lo[a] - margin - (double)org) / cell), qh = std::ceil(((double)cand[k].hi[a] + margin - (double)org) / cell);
+                    ql = ql < 0.0 ? 0.0 : (ql > 255.0 ? 255.0 : ql); qh = qh < 0.0 ? 0.0 : (qh > 255.0 ? 255.0 : qh);
+                    d.w[4 + a] |= (uint32_t)ql << (8 * k);
+                    d.w[7 + a] |= (uint32_t)qh << (8 * k);
+                }
+            }
+            d.w[3] = exps;
             for (int k = 0; k < 4; k++) {
                 if (k >= (int)cand.size()) { d.ref[k] = (int)0x80000000; continue; }
-                uint32_t lo[3], hi[3];
-                for (int a = 0; a < 3; a++) { lo[a] = (uint32_t)qlo_f(cand[k].lo[a], a); hi[a] = (uint32_t)qhi_f(cand[k].hi[a], a); }
-                d.w[3 * k] = lo[0] | (lo[1] << 16); d.w[3 * k + 1] = lo[2] | (hi[0] << 16); d.w[3 * k + 2] = hi[1] | (hi[2] << 16);
                 if (cand[k].ref >= 0) {
                     d.ref[k] = (int)n4.size();
                     n4.push_back(DNode4{});

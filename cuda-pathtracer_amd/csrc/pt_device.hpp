@@ -311,28 +311,32 @@ PT_DEV Hit closest_hit(const DScene& S, F3 o, F3 d, int tid, uint32_t& nbox, uin
     return best;
 }
 
-// One step through a 4-wide node (DNode4: twelve words of 16-bit grid boxes, four child references): the
-// entry distances of the four children against the ray in grid coordinates, culled against the best hit so
-// far, sorted nearest first (1e30 = not to be visited). The plane distances are q * invq + noq in one fused
-// operation each; an axis the ray is parallel to would give inf - inf = NaN on both planes, so the caller keeps
-// invq finite. Boxes on the grid are conservative, so a hit is never lost and the closest hit is exact.
-PT_DEV void wide_step(const float4& n0, const float4& n1, const float4& n2, const float4& n3, F3 invq, F3 noq, float best_t,
+// One step through a 4-wide node (DNode4: a grid origin, a power-of-two cell size per axis, four child boxes as
+// 8-bit grid coordinates, four child references): the entry distances of the four children, culled against the
+// bound `cull` (the best hit so far, taken a little wide), sorted nearest first (1e30 = not to be visited). A plane
+// at q cells from the origin org lies at distance q * (inv * cell) + (org - o) * inv along the ray: one conversion
+// and one fused multiply-add per plane after three subtractions, multiplications and scalings per node. The
+// caller keeps inv finite (an axis the ray is parallel to would give inf - inf = NaN on both planes). Boxes on
+// the grid are conservative, so a hit is never lost and the closest hit is exact.
+PT_DEV void wide_step(const float4& n0, const float4& n1, const float4& n2, const float4& n3, F3 o, F3 inv, float cull,
                       int& r0, int& r1, int& r2, int& r3, float& d0, float& d1, float& d2, float& d3)
 {
-    const uint32_t wd[12] = {__float_as_uint(n0.x), __float_as_uint(n0.y), __float_as_uint(n0.z), __float_as_uint(n0.w),
-                             __float_as_uint(n1.x), __float_as_uint(n1.y), __float_as_uint(n1.z), __float_as_uint(n1.w),
-                             __float_as_uint(n2.x), __float_as_uint(n2.y), __float_as_uint(n2.z), __float_as_uint(n2.w)};
+    const uint32_t ex = __float_as_uint(n0.w);
+    const float sx = __builtin_ldexpf(inv.x, (int)(int8_t)(ex & 255u)), sy = __builtin_ldexpf(inv.y, (int)(int8_t)((ex >> 8) & 255u)),
+                sz = __builtin_ldexpf(inv.z, (int)(int8_t)((ex >> 16) & 255u));
+    const float bx = (n0.x - o.x) * inv.x, by = (n0.y - o.y) * inv.y, bz = (n0.z - o.z) * inv.z;
+    const uint32_t lx = __float_as_uint(n1.x), ly = __float_as_uint(n1.y), lz = __float_as_uint(n1.z);
+    const uint32_t hx = __float_as_uint(n1.w), hy = __float_as_uint(n2.x), hz = __float_as_uint(n2.y);
     r0 = __float_as_int(n3.x); r1 = __float_as_int(n3.y); r2 = __float_as_int(n3.z); r3 = __float_as_int(n3.w);
     float dk[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const uint32_t a = wd[3 * k], b = wd[3 * k + 1], c = wd[3 * k + 2];
-        float t0x = __builtin_fmaf((float)(a & 0xffffu), invq.x, noq.x), t1x = __builtin_fmaf((float)(b >> 16), invq.x, noq.x);
-        float t0y = __builtin_fmaf((float)(a >> 16), invq.y, noq.y),    t1y = __builtin_fmaf((float)(c & 0xffffu), invq.y, noq.y);
-        float t0z = __builtin_fmaf((float)(b & 0xffffu), invq.z, noq.z), t1z = __builtin_fmaf((float)(c >> 16), invq.z, noq.z);
+        float t0x = __builtin_fmaf((float)((lx >> (8 * k)) & 255u), sx, bx), t1x = __builtin_fmaf((float)((hx >> (8 * k)) & 255u), sx, bx);
+        float t0y = __builtin_fmaf((float)((ly >> (8 * k)) & 255u), sy, by), t1y = __builtin_fmaf((float)((hy >> (8 * k)) & 255u), sy, by);
+        float t0z = __builtin_fmaf((float)((lz >> (8 * k)) & 255u), sz, bz), t1z = __builtin_fmaf((float)((hz >> (8 * k)) & 255u), sz, bz);
         float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
         float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
-        dk[k] = (tf > tn && tf > 0.f && tn < best_t) ? tn : 1e30f;
+        dk[k] = (tf > tn && tf > 0.f && tn < cull) ? tn : 1e30f;
     }
     d0 = r0 == PT_TRAV_EMPTY ? 1e30f : dk[0]; d1 = r1 == PT_TRAV_EMPTY ? 1e30f : dk[1];
     d2 = r2 == PT_TRAV_EMPTY ? 1e30f : dk[2]; d3 = r3 == PT_TRAV_EMPTY ? 1e30f : dk[3];
@@ -345,20 +349,20 @@ PT_DEV void wide_step(const float4& n0, const float4& n1, const float4& n2, cons
     cswap(d0, r0, d1, r1); cswap(d2, r2, d3, r3); cswap(d0, r0, d2, r2); cswap(d1, r1, d3, r3); cswap(d1, r1, d2, r2);
 }
 
-// The ray in grid coordinates for wide_step; returns the entry distance of the scene box. The boxes carry two
-// cells of padding (the scene box 0.1 units), so the hardware reciprocal's last-bit error cannot lose one. A
-// huge finite slope stands in for the infinite one of an axis the ray is parallel to: both planes of a slab
-// the origin is outside of stay on the same side.
-PT_DEV float wide_ray(const DScene& S, F3 o, F3 d, F3& invq, F3& noq)
+// The bound a box's entry distance is compared with: the best hit so far plus 2^-14 of it. The wide boxes carry a
+// margin of only a few rounding errors, so that they stay thinner than the offset rays leave a surface with; the
+// comparison is therefore taken wide instead: a triangle whose computed distance ties or undercuts the best hit by a
+// rounding error is still reached. (No hit yet: 1e10 stays far above every distance.)
+PT_DEV float wide_cull(float best_t) { return best_t * 1.00006103515625f; }
+
+// The reciprocal direction for wide_step. The boxes' margin covers the hardware reciprocal's last-bit error. A
+// huge finite slope stands in for the infinite one of an axis the ray is parallel to: both planes of a slab the
+// origin is outside of stay on the same side, and no product is inf * 0.
+PT_DEV F3 wide_inv(F3 d)
 {
     F3 inv = f3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    float troot = box_entry(o, inv, S.root_min, S.root_max);
-    F3 oq = (o - ld3(S.q_origin)) * ld3(S.q_inv_cell);
-    invq = inv * ld3(S.q_cell);
-    invq = f3(__builtin_fminf(__builtin_fmaxf(invq.x, -1e30f), 1e30f), __builtin_fminf(__builtin_fmaxf(invq.y, -1e30f), 1e30f),
-              __builtin_fminf(__builtin_fmaxf(invq.z, -1e30f), 1e30f));
-    noq = f3(-(oq.x * invq.x), -(oq.y * invq.y), -(oq.z * invq.z));
-    return troot;
+    return f3(__builtin_fminf(__builtin_fmaxf(inv.x, -1e30f), 1e30f), __builtin_fminf(__builtin_fmaxf(inv.y, -1e30f), 1e30f),
+              __builtin_fminf(__builtin_fmaxf(inv.z, -1e30f), 1e30f));
 }
 
 // closest_hit over the 4-wide quantized nodes, one ray per lane from start to end (the persistent traversal
@@ -372,9 +376,7 @@ PT_DEV Hit closest_hit_wide(const DScene& S, F3 o, F3 d, int tid, uint32_t& nnod
     int sp = 0;
     Hit best; best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
     if (!finite3(o) || !finite3(d)) return best;
-    F3 invq, noq;
-    float troot = wide_ray(S, o, d, invq, noq);
-    if (!(troot < best.t)) return best;
+    const F3 inv = wide_inv(d);
     int cur = S.root_ref4;
     auto push = [&](int ref, float tn) {
         uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
@@ -391,7 +393,7 @@ PT_DEV Hit closest_hit_wide(const DScene& S, F3 o, F3 d, int tid, uint32_t& nnod
                 e = spill[(sp - LDS_DEPTH) < kSpillDepth ? (sp - LDS_DEPTH) : (kSpillDepth - 1)];
                 asm volatile("" : "+v"(e.x), "+v"(e.y));
             }
-            if (__uint_as_float(e.y) < best.t) return (int)e.x;
+            if (__uint_as_float(e.y) < wide_cull(best.t)) return (int)e.x;
         }
         return PT_TRAV_EMPTY;
     };
@@ -401,7 +403,7 @@ PT_DEV Hit closest_hit_wide(const DScene& S, F3 o, F3 d, int tid, uint32_t& nnod
             float4 n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
             int r0, r1, r2, r3; float d0, d1, d2, d3;
             if (COUNT) nnode += 1;
-            wide_step(n0, n1, n2, n3, invq, noq, best.t, r0, r1, r2, r3, d0, d1, d2, d3);
+            wide_step(n0, n1, n2, n3, o, inv, wide_cull(best.t), r0, r1, r2, r3, d0, d1, d2, d3);
             if (d3 < 1e30f) push(r3, d3);
             if (d2 < 1e30f) push(r2, d2);
             if (d1 < 1e30f) push(r1, d1);

@@ -28,12 +28,20 @@ struct __attribute__((aligned(32))) DNodeQ {
 };
 static_assert(sizeof(DNodeQ) == 32, "compact node must be 32 bytes");
 
-// Four-wide interior node for the production traversal kernel, 64 bytes = one cache line: up to four
-// child boxes on the same 16-bit grid as DNodeQ and their references (PT_TRAV_EMPTY marks an unused
-// child). Made by pulling grandchildren of the binary tree up into their grandparent, largest box
-// first, which halves the number of dependent node fetches per ray.
+// Four-wide interior node for the production traversal kernel, 64 bytes = one cache line: up to four child
+// boxes and their references (PT_TRAV_EMPTY marks an unused child). Made by pulling grandchildren of the
+// binary tree up into their grandparent, largest box first, which halves the number of dependent node fetches
+// per ray. The boxes are the tight bounds of the triangles below each child (recomputed, whatever boxes the
+// uploaded tree carried), widened by a small safety margin and stored as 8-bit coordinates on a grid local to
+// the node: a single-precision origin and a power-of-two cell size per axis, chosen so that the four boxes
+// span at most 255 cells. A flat wall therefore keeps a box a few thousandths of a unit thick, thinner than
+// the 0.01-unit offset at which shadow and bounce rays leave a surface (pathtracer.cu:467,480): such rays do not
+// start inside the boxes of the surface they leave, and a ray that runs along a wall does not cross the box
+// of every triangle of that wall. Rounded outward, the boxes always contain the exact ones, so closest hits
+// do not depend on them, only the number of nodes visited does.
 struct __attribute__((aligned(64))) DNode4 {
-    uint32_t w[12];       // child k: w[3k] = min.x | min.y << 16, w[3k+1] = min.z | max.x << 16, w[3k+2] = max.y | max.z << 16
+    uint32_t w[12];       // w[0..2]: origin x, y, z (float bits); w[3]: log2 of the cell size per axis, one signed byte each (x | y << 8 | z << 16);
+                          // w[4..9]: byte k of each word belongs to child k: min.x, min.y, min.z, max.x, max.y, max.z in cells from the origin; w[10..11]: 0
     int ref[4];           // as DNode
 };
 static_assert(sizeof(DNode4) == 64, "wide node must be 64 bytes");

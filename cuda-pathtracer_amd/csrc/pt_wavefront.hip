@@ -335,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     int cur = PT_TRAV_EMPTY, sp = 0;
     uint32_t slot = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = o, inv = o;
-    // ray in grid coordinates for the compact nodes (uncounted build only)
+    // ray in grid coordinates for the binary compact nodes
     F3 oq = o, invq = o, noq = o;
     constexpr bool QUANT = WIDE || !COUNT;
     Hit best; best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
@@ -347,6 +347,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
 #if PT_STAMPS
     unsigned long long st_iters = 0, st_lanes = 0, st_leafphases = 0, st_refills = 0, st_leaflanes = 0, st_idle = 0, st_tail = 0, st_tail_idle = 0, st_tail_desc = 0, st_tail_t0 = 0, st_t0 = __builtin_amdgcn_s_memtime();
+    uint32_t st_age = 0; unsigned long long st_h64 = 0, st_h128 = 0, st_h256 = 0, st_h512 = 0, st_max = 0;
 #endif
 
     auto push = [&](int ref, float tn) {
@@ -364,13 +365,19 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                 e = spill[(sp - kExtendLds) < kSpillDepth ? (sp - kExtendLds) : (kSpillDepth - 1)];
                 asm volatile("" : "+v"(e.x), "+v"(e.y));    // keep the LDS and the private load apart
             }
-            if (__uint_as_float(e.y) < best.t) return (int)e.x;
+            if (__uint_as_float(e.y) < (WIDE ? wide_cull(best.t) : best.t)) return (int)e.x;
         }
         return PT_TRAV_EMPTY;
     };
     auto retire = [&]() {      // the ray of this lane is finished: publish its hit
         w.hit[slot] = make_float4(best.t, __uint_as_float(best.tri), best.u, best.v);
         has_ray = false;
+#if PT_STAMPS
+        st_h64 += st_age >= 64; st_h128 += st_age >= 128; st_h256 += st_age >= 256; st_h512 += st_age >= 512; st_max = st_age > st_max ? st_age : st_max;
+#if PT_STAMPS > 1
+        if (st_age >= 600) { unsigned long long* dbg = reinterpret_cast<unsigned long long*>(w.counters + WF_CTR_WORDS); dbg[4] = __float_as_uint(o.x); dbg[5] = __float_as_uint(o.y); dbg[6] = __float_as_uint(o.z); dbg[7] = __float_as_uint(d.x); dbg[8] = __float_as_uint(d.y); dbg[9] = __float_as_uint(d.z); dbg[10] = st_age; dbg[11] = __float_as_uint(best.t); }
+#endif
+#endif
     };
 
     for (;;) {
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         const bool do_refill = more && n_idle >= w.refill_lanes;
         const bool leaf_now = at_leaf && (__popcll(leaf_mask) >= w.leaf_vote || desc_mask == 0ull);
 #if PT_STAMPS
-        st_iters++; st_lanes += __popcll(desc_mask); st_leafphases += __any(leaf_now) ? 1 : 0; st_refills += do_refill ? 1 : 0;
+        st_age++; st_iters++; st_lanes += __popcll(desc_mask); st_leafphases += __any(leaf_now) ? 1 : 0; st_refills += do_refill ? 1 : 0;
         st_leaflanes += __popcll(__ballot(leaf_now)); st_idle += n_idle;
         if (!more) { if (!st_tail) st_tail_t0 = __builtin_amdgcn_s_memtime(); st_tail++; st_tail_idle += n_idle; st_tail_desc += __popcll(desc_mask); }
 #endif
@@ -449,25 +456,26 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
 
         // ---- one interior step for every descending lane
         if (descending && WIDE) {
-            // four children: entry distances on the quantized grid, culled against the best hit, then sorted
+            // four children: entry distances on the node's grid, culled against the best hit, then sorted
             // (the same arithmetic as wide_step, written out here: the call, though inlined, measured 7 % slower)
-            const uint32_t wd[12] = {__float_as_uint(n0.x), __float_as_uint(n0.y), __float_as_uint(n0.z), __float_as_uint(n0.w),
-                                     __float_as_uint(n1.x), __float_as_uint(n1.y), __float_as_uint(n1.z), __float_as_uint(n1.w),
-                                     __float_as_uint(n2.x), __float_as_uint(n2.y), __float_as_uint(n2.z), __float_as_uint(n2.w)};
+            const float cull = wide_cull(best.t);
+            const uint32_t ex = __float_as_uint(n0.w);
+            const float sx = __builtin_ldexpf(inv.x, (int)(int8_t)(ex & 255u)), sy = __builtin_ldexpf(inv.y, (int)(int8_t)((ex >> 8) & 255u)),
+                        sz = __builtin_ldexpf(inv.z, (int)(int8_t)((ex >> 16) & 255u));
+            const float bx = (n0.x - o.x) * inv.x, by = (n0.y - o.y) * inv.y, bz = (n0.z - o.z) * inv.z;
+            const uint32_t lx = __float_as_uint(n1.x), ly = __float_as_uint(n1.y), lz = __float_as_uint(n1.z);
+            const uint32_t hx = __float_as_uint(n1.w), hy = __float_as_uint(n2.x), hz = __float_as_uint(n2.y);
             int r0 = __float_as_int(n3.x), r1 = __float_as_int(n3.y), r2 = __float_as_int(n3.z), r3 = __float_as_int(n3.w);
             if (COUNT) tl.box += 1;
             float dk[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const uint32_t a = wd[3 * k], b = wd[3 * k + 1], c = wd[3 * k + 2];
-                // plane distances as q * inv - o * inv in one fused operation each; an axis the ray is parallel to
-                // gives inf - inf = NaN on both planes, which min/max ignore: the box only gets more conservative
-                float t0x = __builtin_fmaf((float)(a & 0xffffu), invq.x, noq.x), t1x = __builtin_fmaf((float)(b >> 16), invq.x, noq.x);
-                float t0y = __builtin_fmaf((float)(a >> 16), invq.y, noq.y),    t1y = __builtin_fmaf((float)(c & 0xffffu), invq.y, noq.y);
-                float t0z = __builtin_fmaf((float)(b & 0xffffu), invq.z, noq.z), t1z = __builtin_fmaf((float)(c >> 16), invq.z, noq.z);
+                float t0x = __builtin_fmaf((float)((lx >> (8 * k)) & 255u), sx, bx), t1x = __builtin_fmaf((float)((hx >> (8 * k)) & 255u), sx, bx);
+                float t0y = __builtin_fmaf((float)((ly >> (8 * k)) & 255u), sy, by), t1y = __builtin_fmaf((float)((hy >> (8 * k)) & 255u), sy, by);
+                float t0z = __builtin_fmaf((float)((lz >> (8 * k)) & 255u), sz, bz), t1z = __builtin_fmaf((float)((hz >> (8 * k)) & 255u), sz, bz);
                 float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
                 float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
-                dk[k] = (tf > tn && tf > 0.f && tn < best.t) ? tn : 1e30f;
+                dk[k] = (tf > tn && tf > 0.f && tn < cull) ? tn : 1e30f;
             }
             float d0 = r0 == PT_TRAV_EMPTY ? 1e30f : dk[0], d1 = r1 == PT_TRAV_EMPTY ? 1e30f : dk[1];
             float d2 = r2 == PT_TRAV_EMPTY ? 1e30f : dk[2], d3 = r3 == PT_TRAV_EMPTY ? 1e30f : dk[3];
@@ -545,13 +553,17 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
             o = f3(ro4.x, ro4.y, ro4.z); d = f3(rd4.x, rd4.y, rd4.z);
             best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
             sp = 0;
+#if PT_STAMPS
+            st_age = 0;
+#endif
             has_ray = true;
             if (COUNT) tl.rays++;
             cur = PT_TRAV_EMPTY;
             if (finite3(o) && finite3(d)) {
                 // the quantized boxes carry two cells of padding (the root box 0.1 units): the hardware reciprocal's
                 // last-bit error cannot lose a box, and saves three IEEE divisions per ray
-                if (QUANT) inv = f3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+                if (WIDE) inv = wide_inv(d);
+                else if (QUANT) inv = f3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
                 else inv = 1.0f / d;
                 if (COUNT && !WIDE) tl.box += 1;
 #if PT_SKIP_ROOT_TEST
@@ -564,7 +576,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                     float troot = box_entry(o, inv, S.root_min, S.root_max);
                     if (troot < best.t) cur = WIDE ? S.root_ref4 : S.root_ref;
                 }
-                if (QUANT) {
+                if (QUANT && !WIDE) {
                     oq = (o - ld3(S.q_origin)) * ld3(S.q_inv_cell);
                     invq = inv * ld3(S.q_cell);
                     // an axis the ray is parallel to: a huge finite slope keeps q * inv - o * inv free of inf - inf and
@@ -579,7 +591,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         }
     }
 #if PT_STAMPS
-    if (lane == 0 && n_chunks * 10u >= (uint32_t)(w.n_slots / kRayChunk) * 9u) {      // full launches only
+    if (n_chunks * 10u >= (uint32_t)(w.n_slots / kRayChunk) * 9u) { unsigned long long* dbg = reinterpret_cast<unsigned long long*>(w.counters + WF_CTR_WORDS); if (st_h64) atomicAdd(dbg + 13, st_h64); if (st_h128) atomicAdd(dbg + 14, st_h128); if (st_h256) atomicAdd(dbg + 15, st_h256); atomicMax(dbg + 2, st_max); }
+    if (PT_STAMPS == 1 && lane == 0 && n_chunks * 10u >= (uint32_t)(w.n_slots / kRayChunk) * 9u) {      // full launches only
         unsigned long long* dbg = reinterpret_cast<unsigned long long*>(w.counters + WF_CTR_WORDS);
         atomicAdd(dbg + 0, __builtin_amdgcn_s_memtime() - st_t0); atomicAdd(dbg + 1, st_refills); atomicAdd(dbg + 3, st_iters);
         atomicAdd(dbg + 4, st_lanes); atomicAdd(dbg + 5, st_leafphases); atomicAdd(dbg + 6, 1ull); atomicAdd(dbg + 7, st_leaflanes); atomicAdd(dbg + 8, st_idle); atomicAdd(dbg + 9, st_tail); atomicAdd(dbg + 10, st_tail_idle); atomicAdd(dbg + 11, st_tail_desc); atomicAdd(dbg + 12, st_tail ? __builtin_amdgcn_s_memtime() - st_tail_t0 : 0ull);

@@ -23,3 +23,4 @@ tail, tail_idle, tail_desc = d[9], d[10], d[11]
 print('tail (no more blocks to take): %.1f %% of the iterations, idle lanes %.1f, descending %.1f; before the tail: idle %.1f, descending %.1f'
       % (100.0 * tail / iters, tail_idle / max(tail, 1), tail_desc / max(tail, 1), (idle - tail_idle) / max(iters - tail, 1), (lanes - tail_desc) / max(iters - tail, 1)))
 print('time in the tail: %.1f %% of the wave cycles' % (100.0 * d[12] / total))
+print('rays that took >= 64 / 128 / 256 passes: %d / %d / %d; longest %d passes' % (d[13], d[14], d[15], d[2]))

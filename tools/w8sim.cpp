@@ -39,6 +39,7 @@ static int build_range(Tree& T, const int* idx, int first, int count)
     T.b.push_back(n);
     return (int)T.b.size() - 1;
 }
+static bool g_tight = false;
 static int convert(Tree& T, const pt_bvh_node* nodes, const int* idx, int i)
 {
     const pt_bvh_node& n = nodes[i];
@@ -47,6 +48,7 @@ static int convert(Tree& T, const pt_bvh_node* nodes, const int* idx, int i)
     BNode b; b.left = l; b.right = r;
     b.box.lo[0] = n.aabbMin.x; b.box.lo[1] = n.aabbMin.y; b.box.lo[2] = n.aabbMin.z;
     b.box.hi[0] = n.aabbMax.x; b.box.hi[1] = n.aabbMax.y; b.box.hi[2] = n.aabbMax.z;
+    if (g_tight) b.box = uni(l < 0 ? T.tribox[~l] : T.b[l].box, r < 0 ? T.tribox[~r] : T.b[r].box);
     T.b.push_back(b);
     return (int)T.b.size() - 1;
 }
@@ -72,9 +74,26 @@ static int count_tris(const Tree& T, int ref, int limit)
 }
 // quant: 0 fp32 boxes, 1: 16-bit global grid (+2 cells), 2: 8-bit local grid on top of the 16-bit global one
 struct Quant { int mode; double org[3], cell[3]; };
+static double g_pad = 0.003;
 static void quantize_node(WNode& n, const Quant& Q)
 {
     if (Q.mode == 0) return;
+    if (Q.mode == 3) {      // local 8-bit frame: fp32 origin, power-of-two cell per axis, boxes padded by g_pad
+        for (int a = 0; a < 3; a++) {
+            double o = 1e300, m = -1e300;
+            for (int k = 0; k < n.n; k++) { o = std::min(o, (double)n.c[k].box.lo[a] - g_pad); m = std::max(m, (double)n.c[k].box.hi[a] + g_pad); }
+            float of = (float)o; if ((double)of > o) of = std::nextafterf(of, -1e30f);
+            int e = -40;
+            while ((m - of) > 255.0 * std::ldexp(1.0, e)) e++;
+            double cell = std::ldexp(1.0, e);
+            for (int k = 0; k < n.n; k++) {
+                double ql = std::floor(((double)n.c[k].box.lo[a] - g_pad - of) / cell), qh = std::ceil(((double)n.c[k].box.hi[a] + g_pad - of) / cell);
+                ql = std::max(0.0, ql); qh = std::min(255.0, qh);
+                n.c[k].box.lo[a] = (float)(of + ql * cell); n.c[k].box.hi[a] = (float)(of + qh * cell);
+            }
+        }
+        return;
+    }
     int glo[8][3], ghi[8][3];
     for (int k = 0; k < n.n; k++) for (int a = 0; a < 3; a++) {
         double lo = std::floor((n.c[k].box.lo[a] - Q.org[a]) / Q.cell[a]) - 2.0, hi = std::ceil((n.c[k].box.hi[a] - Q.org[a]) / Q.cell[a]) + 2.0;
@@ -248,6 +267,7 @@ static void trace(const Wide& Wd, const Tree& T, const float o[3], const float d
 extern "C" int w8sim(const pt_triangle* tris, int ntri, const pt_bvh_node* nodes, const int* idx, const float* rays, int nrays,
                      int W, int leaf_merge, int quant, int octant_slots, int policy, double* out /* steps, tris, stale, pushes, maxsp, nodes, mismatches */)
 {
+    g_tight = quant >= 10; quant %= 10;
     Tree T; T.tris = tris; T.ntri = ntri;
     T.tribox.resize(ntri);
     for (int i = 0; i < ntri; i++) T.tribox[i] = tri_bounds(tris[i]);
@@ -270,5 +290,6 @@ extern "C" int w8sim(const pt_triangle* tris, int ntri, const pt_bvh_node* nodes
     }
     out[0] = (double)steps / nrays; out[1] = (double)ntris / nrays; out[2] = (double)stale / nrays; out[3] = (double)pushes / nrays; out[4] = (double)maxsp;
     out[5] = (double)Wd.nodes.size(); out[6] = 0;
+    { uint64_t mx = 0; for (int i = 0; i < nrays; i++) { Stats S{0,0,0,0,0}; float t; int tri; trace(Wd, T, rays + 8 * (size_t)i, rays + 8 * (size_t)i + 4, policy, S, t, tri); mx = std::max(mx, S.steps); } out[7] = (double)mx; }
     return 0;
 }

@@ -34,21 +34,22 @@ sec = np.zeros(len(hp), RAY_DTYPE); sec['d'] = hemi(len(hp)); sec['o'] = hp + se
 h2 = orc.closest_bvh(S, sec); ok2 = h2['tri'] != 0xFFFFFFFF
 hp2 = sec['o'][ok2] + sec['d'][ok2] * h2['t'][ok2][:, None]
 ter = np.zeros(len(hp2), RAY_DTYPE); ter['d'] = hemi(len(hp2)); ter['d'][:, 1] = np.abs(ter['d'][:, 1]); ter['o'] = hp2 + ter['d'] * 0.05
-rays = np.concatenate([prim, sec, ter, ter])      # bounce and shadow rays dominate a render
+rays = np.concatenate([prim, sec, ter, ter])
+if which == 'atrium':
+    env = np.zeros(len(hp), RAY_DTYPE); th = rng.uniform(0.2, 1.6, len(hp)); env['d'] = np.stack([-np.sin(th), np.cos(th), -0.0 * th], 1); env['o'] = hp; env['o'][:, 2] += 0.01 * np.sign(-hp[:, 2]); env['o'][:, 1] += 0.01
+    rays = np.concatenate([rays, env])      # bounce and shadow rays dominate a render
 print('rays', len(prim), len(sec), len(ter))
 flat = np.zeros((len(rays), 8), np.float32); flat[:, 0:3] = rays['o']; flat[:, 4:7] = rays['d']
 out = (C.c_double * 8)()
 def run(W, merge, quant, octs, policy):
     L.w8sim(tris.ctypes.data_as(C.c_void_p), C.c_int(len(tris)), nodes.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p),
             flat.ctypes.data_as(C.c_void_p), C.c_int(len(flat)), C.c_int(W), C.c_int(merge), C.c_int(quant), C.c_int(octs), C.c_int(policy), out)
-    print('W%d merge%d quant%d oct%d policy%d: steps %.2f tris %.2f stale %.2f pushes %.2f maxsp %d nodes %d' % (W, merge, quant, octs, policy, out[0], out[1], out[2], out[3], out[4], out[5]), flush=True)
+    print('W%d merge%d quant%d oct%d policy%d: steps %.2f tris %.2f stale %.2f pushes %.2f maxsp %d nodes %d longest %d' % (W, merge, quant, octs, policy, out[0], out[1], out[2], out[3], out[4], out[5], out[7]), flush=True)
 run(4, 2, 1, 0, 0)      # the present scheme
-run(4, 1, 1, 0, 0)
-run(8, 1, 0, 0, 0)      # 8-wide, fp32 boxes, sorted, per child
-run(8, 1, 1, 0, 0)
-run(8, 1, 2, 0, 0)      # 8-bit local grid
-run(8, 1, 2, 1, 2)      # octant order, per-child entries
-run(8, 1, 2, 1, 1)      # octant order, group entries with a bound
-run(8, 1, 2, 1, 3)      # octant order, group entries, no distances
-run(8, 2, 2, 1, 1)
-run(8, 2, 2, 0, 0)
+run(4, 2, 11, 0, 0)     # the same on tight boxes recomputed from the triangles
+run(4, 2, 0, 0, 0)      # fp32 boxes as given
+run(4, 2, 10, 0, 0)     # fp32 tight boxes
+run(4, 2, 13, 0, 0)     # local 8-bit frames on tight boxes, pad 0.003
+run(4, 1, 13, 0, 0)
+run(4, 3, 13, 0, 0)
+run(8, 1, 13, 0, 0)
