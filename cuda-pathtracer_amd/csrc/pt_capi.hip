@@ -445,9 +445,13 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
             sub_count[i] = cl + cr;
         }
     }
+    // A subtree becomes one leaf only where that saves work: its triangles' boxes must overlap so much that their
+    // union is no larger (in surface area) than the two halves together, as for the two triangles of a quad. Unrelated
+    // neighbours (a soup of small triangles) keep a box and a test each.
+    std::vector<char> mergeable(dn.size(), 0);
     auto wide_ref = [&](int ref) -> int {       // binary reference -> wide reference (interior stays >= 0, to be renumbered)
         if (ref < 0) { int n = leaf_count(ref); if (n > 16) wide_ok = false; return wide_leaf(~ref, n > 16 ? 16 : n); }
-        if (sub_count[ref] <= leaf_merge && sub_count[ref] <= 16) return wide_leaf(sub_first[ref], sub_count[ref]);
+        if (mergeable[ref] && sub_count[ref] <= leaf_merge && sub_count[ref] <= 16) return wide_leaf(sub_first[ref], sub_count[ref]);
         return ref;
     };
     // Tight bounds of the triangles below each child of every binary node (the boxes the uploaded tree carries may
@@ -472,6 +476,9 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
             for (int i = (int)dn.size() - 1; i >= 0; i--) {       // children have larger indices than their parents
                 tight_l[i] = dn[i].left < 0 ? leaf_bounds(dn[i].left) : join(tight_l[dn[i].left], tight_r[dn[i].left]);
                 tight_r[i] = dn[i].right < 0 ? leaf_bounds(dn[i].right) : join(tight_l[dn[i].right], tight_r[dn[i].right]);
+                auto half_area = [](const TightBox& b) { double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2]; return x * y + y * z + z * x; };
+                const bool parts_ok = (dn[i].left < 0 || mergeable[dn[i].left]) && (dn[i].right < 0 || mergeable[dn[i].right]);
+                mergeable[i] = parts_ok && half_area(join(tight_l[i], tight_r[i])) <= half_area(tight_l[i]) + half_area(tight_r[i]);
             }
         }
         for (const pt_triangle& T : c->tris) {
