@@ -41,7 +41,16 @@ struct Path {
     Mat vm;
     F3 vn;
     bool v_inside;
+    int lobes;               // which lobes of the vertex material carry weight (lobe_class), for queue ordering only
 };
+
+// Which branches DisneyEval_2 / DisneySample_2 take for a material (disney.cuh:267-344): bit 0 diffuse + dielectric
+// reflection, bit 1 metal, bit 2 glass, bit 3 clearcoat. Used to group vertices with like materials in one wave; no
+// result depends on it.
+PT_DEV int lobe_class(const Mat& m)
+{
+    return ((1.0f - m.metal) * (1.0f - m.strans) > 0.f ? 1 : 0) | (m.metal > 0.f ? 2 : 0) | ((1.0f - m.metal) * m.strans > 0.f ? 4 : 0) | (m.coat > 0.f ? 8 : 0);
+}
 
 struct Tally { uint32_t rays, box, tri, verts, envs, taps, taps_r; };
 
@@ -70,7 +79,7 @@ PT_DEV void begin_sample(Path& P, const DCamera& cam, int x, int y, int frame)
     }
     P.o = origin; P.d = rd;
     P.thr = 1.0f; P.pdf = 0.f; P.result = 0.f;
-    P.bounce = 0; P.inside = false; P.surface_scatter = false;
+    P.bounce = 0; P.inside = false; P.surface_scatter = false; P.lobes = 0;
     P.state = ST_PATH;
     P.ch = 0;
     if (cam.is_rendering) {
@@ -185,6 +194,7 @@ PT_DEV void on_path_hit(const DScene& S, const DCamera& cam, Path& P, Surf& info
     info.m.rough = pt_fmaxf(info.m.rough, 0.0001f);
     P.surface_scatter = false;
     P.vm = info.m; P.vn = info.n; P.v_inside = info.inside;
+    P.lobes = lobe_class(info.m);
     if (info.inside) {
         F3 sigT = info.m.sigA + info.m.sigS;
         float zeta = rng_next(P.rng);

@@ -34,18 +34,18 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kPlanThreads = 1024;      // the single-workgroup planning kernels
 
-// flags word: state[1:0] ch[3:2] inside[4] surface_scatter[5] sh_inside[6] nee_surface[7] nee_skip[8] v_inside[9] seg[15:10]
+// flags word: state[1:0] ch[3:2] inside[4] surface_scatter[5] sh_inside[6] nee_surface[7] nee_skip[8] v_inside[9] seg[15:10] lobes[19:16]
 PT_DEV uint32_t pack_flags(const Path& P)
 {
     return (uint32_t)P.state | ((uint32_t)(P.ch & 3) << 2) | ((uint32_t)P.inside << 4) | ((uint32_t)P.surface_scatter << 5) |
            ((uint32_t)P.sh_inside << 6) | ((uint32_t)P.nee_surface << 7) | ((uint32_t)P.nee_skip << 8) | ((uint32_t)P.v_inside << 9) |
-           ((uint32_t)(P.seg & 63) << 10);
+           ((uint32_t)(P.seg & 63) << 10) | ((uint32_t)(P.lobes & 15) << 16);
 }
 PT_DEV void unpack_flags(Path& P, uint32_t f)
 {
     P.state = (int)(f & 3u); P.ch = (int)((f >> 2) & 3u); P.inside = (f >> 4) & 1u; P.surface_scatter = (f >> 5) & 1u;
     P.sh_inside = (f >> 6) & 1u; P.nee_surface = (f >> 7) & 1u; P.nee_skip = (f >> 8) & 1u; P.v_inside = (f >> 9) & 1u;
-    P.seg = (int)((f >> 10) & 63u);
+    P.seg = (int)((f >> 10) & 63u); P.lobes = (int)((f >> 16) & 15u);
 }
 
 struct SampleId { int x, y, frame; uint32_t pixel; uint32_t stage_index; };
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
     Path P;                                        // n_slots is a multiple of the workgroup size: no tail
     P.state = ST_DONE; P.result = 0.f; P.ch = 0; P.rng.draws = 0;
     P.inside = P.surface_scatter = P.sh_inside = P.nee_surface = P.nee_skip = P.v_inside = false;
-    P.seg = 0; P.bounce = 0; P.thr = 1.f; P.pdf = 0.f;
+    P.seg = 0; P.bounce = 0; P.thr = 1.f; P.pdf = 0.f; P.lobes = 0;
     P.o = P.d = P.so = P.sd = P.light = P.env_color = f3(0.f, 0.f, 0.f); P.env_pdf = 0.f;
     uint32_t sample = 0xFFFFFFFFu;
     SampleId id = decode_sample(w, 0);
@@ -636,20 +636,37 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE
         }
         finished = P.state == ST_DONE;
     }
-    // slots that reached the bsdf stage: append to the queue
-    // compacted per workgroup (no global atomics): block b owns queue entries [b*256, b*256 + count[b])
+    // Slots that reached the bsdf stage go into the workgroup's segment of the queue (block b owns entries
+    // [b*256, b*256 + count[b]); no global atomics), ordered by the kind of work the stage will do for them: which
+    // lobes the material carries (the branches of DisneyEval_2, disney.cuh:294-344), surface or medium vertex, and
+    // whether the light sample arrived (its evaluation is skipped otherwise, pathtracer.cu:318). A counting sort in
+    // LDS: the waves of the bsdf stage then run mostly one kind each instead of every branch for a few lanes.
     bool to_bsdf = live && P.state == ST_AFTER;
     {
-        __shared__ uint32_t s_cnt[kBlock / 64];
-        unsigned long long qm = __ballot(to_bsdf);
-        const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-        if (lane == 0) s_cnt[wid] = (uint32_t)__popcll(qm);
+        constexpr int kKinds = 64;
+        __shared__ uint32_t s_kind[kKinds];
+        if (threadIdx.x < kKinds) s_kind[threadIdx.x] = 0u;
         __syncthreads();
-        uint32_t base = 0, total = 0;
+        uint32_t kind = 0, rank = 0;
+        if (to_bsdf) {
+            const bool lit = !P.nee_skip && !(dot(P.light, P.light) <= 0.05f);
+            kind = (uint32_t)(P.lobes & 15) | (P.nee_surface ? 0u : 16u) | (lit ? 32u : 0u);
+            rank = atomicAdd(&s_kind[kind], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {         // exclusive prefix over the kinds, one per lane of the first wave
+            const uint32_t mine = s_kind[threadIdx.x];
+            uint32_t incl = mine;
 #pragma unroll
-        for (int j = 0; j < kBlock / 64; j++) { uint32_t cj = s_cnt[j]; if (j < wid) base += cj; total += cj; }
-        if (to_bsdf) w.bsdf_queue[(size_t)blockIdx.x * kBlock + base + (uint32_t)__popcll(qm & ((1ull << lane) - 1ull))] = slot;
-        if (threadIdx.x == 0) w.bsdf_count[blockIdx.x] = total;
+            for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                uint32_t t = (uint32_t)__shfl_up((int)incl, dlt, 64);
+                if ((int)threadIdx.x >= dlt) incl += t;
+            }
+            s_kind[threadIdx.x] = incl - mine;
+            if (threadIdx.x == 63) w.bsdf_count[blockIdx.x] = incl;
+        }
+        __syncthreads();
+        if (to_bsdf) w.bsdf_queue[(size_t)blockIdx.x * kBlock + s_kind[kind] + rank] = slot;
     }
     finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples, false);
     if (live) {
