@@ -7,6 +7,10 @@
 #include <vector>
 #include <functional>
 #include <new>
+#include <string>
+#include <thread>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include "../../include/pt_capi.h"
 #include "../../include/pt_detmath.h"
 #include "pt_internal.h"
@@ -1558,5 +1562,121 @@ int pt_build_env_cdf(const float* rgba, int w, int h, float* cdf_out, float* sum
     return PT_OK;
 }
 void pt_free(void* p) { free(p); }
+
+// ---------------------------------------------------------------- several GPUs in one process
+// The render shards by sample: every (pixel, frame) owns a random stream and frames meet only in the accumulator
+// sum (pathtracer.cu:560,583-586). A group holds one context per GPU with the same scene uploaded to each; a render
+// gives context r of n the frames [begin + r*F/n, begin + (r+1)*F/n), one host thread per context, and sums the
+// fp32 accumulators onto the first context with ONE reduce over xGMI (RCCL); no other exchange exists. RCCL is
+// looked up at run time when a group of more than one GPU is made, so single-GPU users never load it.
+namespace {
+struct Rccl {
+    void* handle = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load()
+    {
+        if (handle) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so"}) { handle = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (handle) break; }
+        if (!handle) { set_error("pt_group_create: cannot load RCCL (%s)", dlerror()); return false; }
+        auto sym = [&](const char* n) { void* p = dlsym(handle, n); if (!p) set_error("pt_group_create: RCCL lacks %s", n); return p; };
+        CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        Reduce = (decltype(Reduce))sym("ncclReduce");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        return CommInitAll && CommDestroy && Reduce && GroupStart && GroupEnd && GetErrorString;
+    }
+};
+Rccl g_rccl;
+}
+
+struct pt_group {
+    std::vector<pt_ctx*> ctx;
+    std::vector<ncclComm_t> comm;     // empty for a group of one
+};
+
+int pt_group_frames(int frame_begin, int frame_end, int n, int r, int* first_out, int* last_out)
+{
+    if (n < 1 || r < 0 || r >= n || frame_end < frame_begin || !first_out || !last_out) { set_error("pt_group_frames: bad argument"); return PT_ERR_ARG; }
+    const long long F = (long long)frame_end - frame_begin;
+    *first_out = frame_begin + (int)(F * r / n);
+    *last_out = frame_begin + (int)(F * (r + 1) / n);
+    return PT_OK;
+}
+
+int pt_group_create(pt_ctx** ctxs, int n, pt_group** out)
+{
+    if (!out) { set_error("pt_group_create: null output"); return PT_ERR_ARG; }
+    *out = nullptr;
+    if (!ctxs || n < 1 || n > 64) { set_error("pt_group_create: 1 to 64 contexts"); return PT_ERR_ARG; }
+    for (int i = 0; i < n; i++) {
+        if (!ctxs[i] || !ctxs[i]->accum) { set_error("pt_group_create: context %d is not initialised", i); return PT_ERR_STATE; }
+        if (ctxs[i]->W != ctxs[0]->W || ctxs[i]->H != ctxs[0]->H) { set_error("pt_group_create: context %d has another image size", i); return PT_ERR_ARG; }
+        for (int j = 0; j < i; j++) if (ctxs[j]->device == ctxs[i]->device) { set_error("pt_group_create: contexts %d and %d share GPU %d; a group takes one context per GPU", j, i, ctxs[i]->device); return PT_ERR_ARG; }
+    }
+    pt_group* g = new (std::nothrow) pt_group();
+    if (!g) { set_error("out of memory"); return PT_ERR_NOMEM; }
+    g->ctx.assign(ctxs, ctxs + n);
+    if (n > 1) {
+        if (!g_rccl.load()) { delete g; return PT_ERR_STATE; }
+        std::vector<int> devs(n);
+        for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
+        g->comm.resize(n);
+        ncclResult_t r = g_rccl.CommInitAll(g->comm.data(), n, devs.data());
+        if (r != ncclSuccess) { set_error("ncclCommInitAll failed: %s", g_rccl.GetErrorString(r)); delete g; return PT_ERR_HIP; }
+    }
+    *out = g;
+    return PT_OK;
+}
+
+void pt_group_destroy(pt_group* g)
+{
+    if (!g) return;
+    for (size_t i = 0; i < g->comm.size(); i++) { (void)hipSetDevice(g->ctx[i]->device); (void)g_rccl.CommDestroy(g->comm[i]); }
+    delete g;
+}
+
+int pt_group_render(pt_group* g, const pt_params* P, int frame_begin, int frame_end)
+{
+    if (!g || !P || frame_end < frame_begin) { set_error("pt_group_render: bad argument"); return PT_ERR_ARG; }
+    const int n = (int)g->ctx.size();
+    // contexts 1.. start from zero: what they render is added onto context 0, which keeps what it holds (as
+    // pt_render_headless adds onto the accumulator)
+    std::vector<int> rc(n, PT_OK);
+    std::vector<std::string> msg(n);
+    auto work = [&](int r) {
+        int f0 = 0, f1 = 0;
+        int e = pt_group_frames(frame_begin, frame_end, n, r, &f0, &f1);
+        if (e == PT_OK && r > 0) e = pt_clear_accum(g->ctx[r]);
+        if (e == PT_OK) e = pt_render_headless(g->ctx[r], P, f0, f1);
+        rc[r] = e;
+        if (e != PT_OK) msg[r] = pt_last_error();       // messages are per thread
+    };
+    std::vector<std::thread> threads;
+    for (int r = 1; r < n; r++) threads.emplace_back(work, r);
+    work(0);
+    for (std::thread& t : threads) t.join();
+    for (int r = 0; r < n; r++) if (rc[r] != PT_OK) { set_error("GPU %d: %s", g->ctx[r]->device, msg[r].c_str()); return rc[r]; }
+    if (n > 1) {
+        // one reduce, enqueued behind each context's render on that context's stream
+        const size_t count = (size_t)g->ctx[0]->W * g->ctx[0]->H * 3;
+        ncclResult_t r = g_rccl.GroupStart();
+        for (int i = 0; i < n && r == ncclSuccess; i++) {
+            if (hipSetDevice(g->ctx[i]->device) != hipSuccess) { r = ncclUnhandledCudaError; break; }
+            r = g_rccl.Reduce(g->ctx[i]->accum, g->ctx[i]->accum, count, ncclFloat, ncclSum, 0, g->comm[i], g->ctx[i]->stream);
+        }
+        ncclResult_t e = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = e;
+        if (r != ncclSuccess) { set_error("ncclReduce failed: %s", g_rccl.GetErrorString(r)); return PT_ERR_HIP; }
+    }
+    for (int i = 0; i < n; i++) { int e = pt_sync(g->ctx[i]); if (e != PT_OK) return e; }
+    return PT_OK;
+}
 
 } // extern "C"

@@ -45,7 +45,9 @@ void usage()
         "  --out FILE.png    displayed image (default out.png)    --pfm FILE.pfm   fp32 accumulator\n"
         "  --exr FILE.exr    linear radiance (accumulator / frames), 32-bit float OpenEXR\n"
         "  --resume FILE.pfm --resume-frames K   continue from a saved accumulator of K frames\n"
-        "  --gpu ID          device (default 0)\n");
+        "  --gpu ID          device (default 0); with --gpus the first of the devices used\n"
+        "  --gpus N          render on N GPUs: the scene goes to each, GPU r renders samples [r*spp/N, (r+1)*spp/N), and one\n"
+        "                    RCCL reduce sums the accumulators onto the first GPU, which writes the outputs\n");
     std::exit(2);
 }
 
@@ -66,7 +68,7 @@ bool parse_floats(const char* s, float* out, int n)
 int main(int argc, char** argv)
 {
     std::string obj, dir, subdir, hdr, out = "out.png", pfm, exr, resume;
-    int W = 1920, H = 1080, spp = 64, bounces = 512, gpu = 0, per_call = 0, resume_frames = 0;
+    int W = 1920, H = 1080, spp = 64, bounces = 512, gpu = 0, per_call = 0, resume_frames = 0, gpus = 1;
     float origin[3] = {0.f, 1.5f, 5.f}, angle[2] = {0.f, 0.f}, fov = 1.f, dof = 0.f, focal = 200.f, post[3] = {1.f, 1.f, 1.f};
     bool preview = false, sunsky = false, use_post = false, general = false;
     float scale = 100.f;
@@ -86,6 +88,7 @@ int main(int argc, char** argv)
         else if (a == "--spp") spp = std::atoi(val());
         else if (a == "--bounces") bounces = std::atoi(val());
         else if (a == "--gpu") gpu = std::atoi(val());
+        else if (a == "--gpus") gpus = std::atoi(val());
         else if (a == "--frames-per-call") per_call = std::atoi(val());
         else if (a == "--origin") { if (!parse_floats(val(), origin, 3)) usage(); }
         else if (a == "--angle") { if (!parse_floats(val(), angle, 2)) usage(); }
@@ -99,7 +102,8 @@ int main(int argc, char** argv)
         else if (a == "--sunsky") sunsky = true;
         else usage();
     }
-    if (obj.empty() || (hdr.empty() && !sunsky) || W <= 0 || H <= 0 || spp <= 0) usage();
+    if (obj.empty() || (hdr.empty() && !sunsky) || W <= 0 || H <= 0 || spp <= 0 || gpus < 1 || gpus > 64) usage();
+    if (gpus > 1 && per_call == 1) { std::fprintf(stderr, "ptamd_render: --frames-per-call 1 renders on one GPU\n"); return 2; }
 
     // kernel parameters as main.cpp:181-202 sets them
     pt_params P;
@@ -133,37 +137,45 @@ int main(int argc, char** argv)
     must(pt_host_build_bvh(pt_host_scene_triangles(hs), pt_host_scene_tri_idx(hs), n_tri, PT_BVH_REFERENCE, nodes.data(), &nodes_used), "BVH build");
     std::printf("BVH: %d nodes (%.2f s)\n", nodes_used, seconds());
 
-    pt_ctx* ctx = nullptr;
-    must(pt_create(&ctx, gpu), "opening the GPU");
-    must(pt_init(ctx, &P), "init");
+    // textures and the environment are decoded once, then every GPU gets the whole scene
+    struct Tex { float* texels; int w, h, comps; };
+    std::vector<Tex> tex(n_tex);
     for (int i = 0; i < n_tex; i++) {           // handles are issued in request order, which is what the materials hold
-        const char* path = nullptr; int comps = 0;
-        must(pt_host_scene_texture_info(hs, i, &path, &comps), "texture list");
-        float* texels = nullptr; int tw = 0, th = 0;
-        must(pt_load_texture_image(path, comps, &texels, &tw, &th), "decoding a texture");
-        uint64_t handle = 0;
-        must(pt_upload_texture(ctx, texels, tw, th, comps, &handle), "texture upload");
-        pt_free(texels);
-        if (handle != (uint64_t)(i + 1)) { std::fprintf(stderr, "ptamd_render: texture handle order changed\n"); return 1; }
+        const char* path = nullptr;
+        must(pt_host_scene_texture_info(hs, i, &path, &tex[i].comps), "texture list");
+        must(pt_load_texture_image(path, tex[i].comps, &tex[i].texels, &tex[i].w, &tex[i].h), "decoding a texture");
     }
-    must(pt_upload_triangles(ctx, pt_host_scene_tri_idx(hs), pt_host_scene_triangles(hs), n_tri), "triangles");
-    must(pt_upload_materials(ctx, pt_host_scene_materials(hs), n_mat), "materials");
-    must(pt_upload_bvh(ctx, nodes.data(), 0, nodes_used, n_tri), "BVH upload");
+    float* env_rgba = nullptr; int ew = 0, eh = 0; float env_sum = 0.f;
+    std::vector<float> cdf;
+    if (!hdr.empty()) {             // updateSkyMap
+        must(pt_load_hdr(hdr.c_str(), &env_rgba, &ew, &eh), "environment map");
+        cdf.resize((size_t)ew * eh);
+        must(pt_build_env_cdf(env_rgba, ew, eh, cdf.data(), &env_sum), "environment CDF");
+    }
+    std::vector<pt_ctx*> ctxs(gpus, nullptr);
+    for (int g = 0; g < gpus; g++) {
+        pt_ctx*& c = ctxs[g];
+        must(pt_create(&c, gpu + g), "opening the GPU");
+        must(pt_init(c, &P), "init");
+        for (int i = 0; i < n_tex; i++) {
+            uint64_t handle = 0;
+            must(pt_upload_texture(c, tex[i].texels, tex[i].w, tex[i].h, tex[i].comps, &handle), "texture upload");
+            if (handle != (uint64_t)(i + 1)) { std::fprintf(stderr, "ptamd_render: texture handle order changed\n"); return 1; }
+        }
+        must(pt_upload_triangles(c, pt_host_scene_tri_idx(hs), pt_host_scene_triangles(hs), n_tri), "triangles");
+        must(pt_upload_materials(c, pt_host_scene_materials(hs), n_mat), "materials");
+        must(pt_upload_bvh(c, nodes.data(), 0, nodes_used, n_tri), "BVH upload");
+        if (env_rgba) must(pt_upload_envmap(c, env_rgba, cdf.data(), ew, eh, env_sum, &P), "environment upload");
+        must(pt_set_sky_mode(c, sunsky ? PT_SKY_SUNSKY : PT_SKY_ENVMAP), "sky mode");
+        must(pt_set_max_bounces(c, bounces), "bounce cap");
+    }
+    for (Tex& t : tex) pt_free(t.texels);
+    if (env_rgba) pt_free(env_rgba);
     pt_host_scene_free(hs);
-
-    // ---- updateSkyMap
-    if (!hdr.empty()) {
-        float* rgba = nullptr; int ew = 0, eh = 0;
-        must(pt_load_hdr(hdr.c_str(), &rgba, &ew, &eh), "environment map");
-        std::vector<float> cdf((size_t)ew * eh);
-        float sum = 0.f;
-        must(pt_build_env_cdf(rgba, ew, eh, cdf.data(), &sum), "environment CDF");
-        must(pt_upload_envmap(ctx, rgba, cdf.data(), ew, eh, sum, &P), "environment upload");
-        pt_free(rgba);
-    }
-    must(pt_set_sky_mode(ctx, sunsky ? PT_SKY_SUNSKY : PT_SKY_ENVMAP), "sky mode");
-    must(pt_set_max_bounces(ctx, bounces), "bounce cap");
-    std::printf("scene on the GPU (%.2f s)\n", seconds());
+    pt_ctx* ctx = ctxs[0];
+    pt_group* group = nullptr;
+    if (gpus > 1) must(pt_group_create(ctxs.data(), gpus, &group), "grouping the GPUs");
+    std::printf("scene on %d GPU%s (%.2f s)\n", gpus, gpus > 1 ? "s" : "", seconds());
 
     // ---- frames
     int first = 0;
@@ -180,6 +192,8 @@ int main(int argc, char** argv)
     if (per_call == 1) {
         P.pixelBuffer = rgba.data();
         for (int f = first; f < first + spp; f++) { P.frameIndex = f; must(pt_render_frame(ctx, &P), "render"); }
+    } else if (group) {
+        must(pt_group_render(group, &P, first, first + spp), "render");
     } else {
         must(pt_render_headless(ctx, &P, first, first + spp), "render");
         must(pt_sync(ctx), "render");
@@ -200,6 +214,7 @@ int main(int argc, char** argv)
         if (!pfm.empty()) must(pt_save_pfm(pfm.c_str(), acc.data(), W, H), "writing the accumulator");
         if (!exr.empty()) must(pt_save_exr(exr.c_str(), acc.data(), W, H, 1.0f / (float)total), "writing the radiance image");
     }
-    pt_destroy(ctx);
+    pt_group_destroy(group);
+    for (pt_ctx* c : ctxs) pt_destroy(c);
     return 0;
 }

@@ -21,7 +21,7 @@ PT_NOALLOC_MAX_RAYS = 262144     # include/pt_capi.h
 EXPORTS = [
     'pt_last_error', 'pt_create', 'pt_destroy', 'pt_set_stream', 'pt_init', 'pt_clear_accum', 'pt_upload_triangles',
     'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_set_frame_lookahead', 'pt_upload_texture', 'pt_upload_envmap',
-    'pt_set_sky_mode', 'pt_set_env_guides', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_set_repack', 'pt_wavefront_stats', 'pt_set_lanes', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
+    'pt_set_sky_mode', 'pt_set_env_guides', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_set_repack', 'pt_wavefront_stats', 'pt_set_lanes', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_group_create', 'pt_group_frames', 'pt_group_render', 'pt_group_destroy', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
     'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_save_exr', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
     'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_trace_closest_noalloc_dev', 'pt_debug_words', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
     'pt_detmath_probe', 'pt_bsdf_probe', 'pt_unorm8_probe', 'pt_set_texture_packing', 'pt_read_obj', 'pt_read_obj_general', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
@@ -50,6 +50,7 @@ def lib():
         L.pt_free.argtypes = [C.c_void_p]
         L.pt_destroy.argtypes = [C.c_void_p]
         L.pt_host_scene_free.argtypes = [C.c_void_p]
+        L.pt_group_destroy.argtypes = [C.c_void_p]
         for n in ('pt_host_scene_triangles', 'pt_host_scene_tri_idx', 'pt_host_scene_materials'):
             getattr(L, n).argtypes = [C.c_void_p]
         _lib = L
@@ -398,3 +399,27 @@ class Renderer:
         out = np.zeros((len(x), 12), dtype=np.float32)
         check(lib().pt_detmath_probe(self.h, _p(x), _p(y), C.c_int(len(x)), _p(out)))
         return out
+
+
+class Group:
+    """pt_group: one Renderer per GPU with the same scene; render() shards frames and reduces onto the first."""
+
+    def __init__(self, renderers):
+        self.renderers = list(renderers)
+        arr = (C.c_void_p * len(self.renderers))(*[r.h for r in self.renderers])
+        self.h = C.c_void_p()
+        check(lib().pt_group_create(arr, C.c_int(len(self.renderers)), C.byref(self.h)))
+
+    def render(self, params, frame_begin, frame_end):
+        check(lib().pt_group_render(self.h, C.byref(params), C.c_int(frame_begin), C.c_int(frame_end)))
+
+    def close(self):
+        if self.h:
+            lib().pt_group_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+def group_frames(frame_begin, frame_end, n, r):
+    a, b = C.c_int(), C.c_int()
+    check(lib().pt_group_frames(C.c_int(frame_begin), C.c_int(frame_end), C.c_int(n), C.c_int(r), C.byref(a), C.byref(b)))
+    return a.value, b.value

@@ -198,6 +198,19 @@ int pt_save_pfm(const char* path, const float* rgb, int w, int h);       /* fp32
 int pt_save_exr(const char* path, const float* rgb, int w, int h, float scale); /* rgb * scale (1 / frames: linear radiance) as an uncompressed 32-bit float scan-line OpenEXR file; the reference only saves the tone-mapped PNG (main.cpp:96-114) */
 int pt_load_pfm(const char* path, float** rgb_out, int* w, int* h);      /* read it back (free with pt_free); feed pt_write_accum to resume */
 
+/* ---- several GPUs in one process (the reference is single-GPU: pathtracer.cu:48 cudaSetDevice(0)) ----
+ * A group holds one initialised context per GPU, each with the same scene uploaded. pt_group_render shards frames
+ * [begin, end) by sample: context r of n renders pt_group_frames' range on its GPU (one host thread each); contexts 1..
+ * are cleared first, and one RCCL reduce over xGMI adds every accumulator onto context 0's, which keeps what it held
+ * (so calls compose like pt_render_headless). The sum order differs from one GPU's frame order: equal to rounding
+ * (1e-4 relative), not bit for bit. Resolve, read or save through context 0. RCCL is loaded when a group of more than
+ * one GPU is created. */
+typedef struct pt_group pt_group;
+int pt_group_create(pt_ctx** ctxs, int n, pt_group** out);
+int pt_group_frames(int frame_begin, int frame_end, int n, int r, int* first_out, int* last_out); /* [begin + r*F/n, begin + (r+1)*F/n), F = end - begin */
+int pt_group_render(pt_group* g, const pt_params* params, int frame_begin, int frame_end);        /* returns when every GPU is done and context 0 holds the sum */
+void pt_group_destroy(pt_group* g);                                      /* the contexts stay the caller's */
+
 /* ---- closest-hit batch (test and measurement entry) ---- */
 int pt_trace_closest(pt_ctx* ctx, const pt_ray* rays, int n, pt_hit* hits_out);
 int pt_trace_closest_dev(pt_ctx* ctx, const pt_ray* rays_dev, int n, pt_hit* hits_dev);

@@ -568,3 +568,17 @@ def test_two_rank_sample_partition_with_gloo_reduce(tmp_path):
     mp.spawn(_gloo_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     err, byte_diff, total = np.load(os.path.join(str(tmp_path), 'result.npy'))
     assert total > 0 and err <= 1e-4 and byte_diff <= 1
+
+
+def test_group_frame_ranges_partition_a_render():
+    """pt_group_frames (the C++ multi-GPU path) deals frames as partition.split_frames does: disjoint, in order, complete."""
+    for begin, end, n in ((0, 4096, 8), (5, 1029, 8), (0, 7, 4), (3, 3, 2), (0, 1, 3), (100, 164, 1)):
+        edges = [lib.group_frames(begin, end, n, r) for r in range(n)]
+        assert edges[0][0] == begin and edges[-1][1] == end
+        for r in range(n):
+            a, b = partition.split_frames(end - begin, n, r)
+            assert edges[r] == (begin + a, begin + b)
+            if r:
+                assert edges[r][0] == edges[r - 1][1]
+    with pytest.raises(ptamd.PtError):
+        lib.group_frames(0, 4, 2, 2)

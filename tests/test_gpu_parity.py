@@ -627,3 +627,22 @@ def test_gpu_built_tree_gives_the_same_image():
         ref = orc.closest_brute(orc.Scene(tris, s.mats), rr)
         assert np.array_equal(got['tri'], ref['tri']) and np.array_equal(bits(got['t']), bits(ref['t'])), n
         r.close()
+
+
+def test_group_of_one_gpu_and_group_errors():
+    """pt_group_render on one GPU is pt_render_headless; two contexts on one GPU are refused (a group takes one
+    context per GPU; the RCCL reduce between GPUs cannot be exercised on a one-GPU machine)."""
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(40, 24))
+    want, _ = orc.render(b.oracle(P), P, 2, 7, 6)
+    r = b.renderer(P)
+    r.set_max_bounces(6)
+    g = lib.Group([r])
+    g.render(P, 2, 4)
+    g.render(P, 4, 7)           # calls compose onto the first context's accumulator
+    _assert_radiance(r.read_accum(), want)
+    g.close()
+    r2 = b.renderer(P)
+    with pytest.raises(ptamd.PtError, match='share GPU'):
+        lib.Group([r, r2])
+    r.close(); r2.close()
