@@ -196,6 +196,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     extend_ms, extend_launches = r.stage_timing(False)
+    image_mean = float(accum.mean().item()) / step_spp if rank == 0 else 0.0      # of the last step's reduced image (a checksum for N-GPU vs 1-GPU runs)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -264,7 +265,7 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 3),
             'higher_is_better': True, 'scaling': 'strong' if strong else 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'samples_per_s': round(tot['samples'] / elapsed, 1),
+            'samples_per_s': round(tot['samples'] / elapsed, 1), 'image_mean': image_mean,
             'rays_per_sample': round(tot['rays'] / tot['samples'], 3),
             'config': {'workload': '%s %dx%d, %s, bounce cap %d'
                                    % (workload_name, W, H, ('%d spp per step over all GPUs' % args.total_spp) if strong else ('%d spp per GPU per step' % spp), args.bounces),

@@ -646,3 +646,38 @@ def test_group_of_one_gpu_and_group_errors():
     with pytest.raises(ptamd.PtError, match='share GPU'):
         lib.Group([r, r2])
     r.close(); r2.close()
+
+
+def test_bench_two_ranks_on_one_gpu_match_one_rank():
+    """bench.py itself under torch.distributed.run with two ranks sharing the GPU (gloo backend; RCCL needs one GPU per
+    rank): the sample partition, the reduce onto rank 0 and the JSON line. With a fixed total sample count (strong
+    scaling) two ranks render the frames one rank renders, so the reduced image agrees to rounding."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    bench = os.path.join(util.ROOT, 'bench.py')
+    common = ['--steps', '1', '--warmup', '0', '--no-cpu', '--width', '160', '--height', '96', '--detail', '0.3', '--device', '0', '--bounces', '8']
+
+    def run(n, extra):
+        if n == 1:
+            cmd = [sys.executable, bench, '--gpus', '1'] + common + extra
+        else:
+            with socket.socket() as s:
+                s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]
+            cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1', '--master-port', str(port),
+                   bench, '--gpus', str(n), '--backend', 'gloo'] + common + extra
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=280)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
+
+    one = run(1, ['--total-spp', '6'])
+    two = run(2, ['--total-spp', '6'])
+    assert one['scaling'] == two['scaling'] == 'strong' and two['n_gpus'] == 2
+    assert one['image_mean'] > 0 and abs(two['image_mean'] - one['image_mean']) <= 1e-4 * one['image_mean']
+    assert two['value'] > 0 and two['roofline']['own_walk_per_ray']['wide_nodes'] > 0
+    weak = run(2, ['--spp', '3'])
+    assert weak['scaling'] == 'weak' and weak['n_gpus'] == 2 and weak['image_mean'] > 0
+    # weak mode: 3 spp per rank = frames [0, 6) in all, the same image again
+    assert abs(weak['image_mean'] - one['image_mean']) <= 1e-4 * one['image_mean']
