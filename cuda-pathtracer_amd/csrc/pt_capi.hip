@@ -7,6 +7,7 @@
 #include <vector>
 #include <functional>
 #include <new>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <dlfcn.h>
@@ -329,6 +330,10 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     if (!c->have_tris || n_tri != (int)c->tris.size()) { set_error("pt_upload_bvh: upload %d triangles first", n_tri); return PT_ERR_STATE; }
     if (root_idx < 0 || root_idx >= nodes_used) { set_error("pt_upload_bvh: bad root"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
+    const bool timing = getenv("PT_BUILD_TIMING") != nullptr;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_mark = now();
+    auto lap = [&](const char* what) { if (timing) { double t = now(); fprintf(stderr, "pt_upload_bvh: %-28s %.3f s\n", what, t - t_mark); t_mark = t; } };
     std::vector<DNode> dn;
     std::vector<DTri> dt;
     dn.reserve(nodes_used / 2 + 1);
@@ -390,6 +395,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     c->scene.root_min[0] = root.aabbMin.x; c->scene.root_min[1] = root.aabbMin.y; c->scene.root_min[2] = root.aabbMin.z;
     c->scene.root_max[0] = root.aabbMax.x; c->scene.root_max[1] = root.aabbMax.y; c->scene.root_max[2] = root.aabbMax.z;
     // 16-bit grid over the (padded) root box for the compact nodes
+    lap("binary nodes, leaf order");
     std::vector<DNodeQ> qn(dn.size());
     std::function<uint16_t(float, int)> qlo_f, qhi_f;
     {
@@ -416,6 +422,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
             t.left = s.left; t.right = s.right;
         }
     }
+    lap("binary quantized nodes");
     // four-wide nodes: each binary node's children are replaced by their own children, largest box first,
     // until four are present; absorbed binary nodes disappear
     std::vector<DNode4> n4;
@@ -462,6 +469,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     // be padded, as the reference builder's are by 0.1 per vertex, BVH_builder.cpp:19-24), and the safety margin the
     // wide boxes get instead: 2^-19 of the largest coordinate, a few times the rounding of the box and triangle tests.
     struct TightBox { float lo[3], hi[3]; };
+    lap("stack need, subtree counts");
     std::vector<TightBox> tight_l(dn.size()), tight_r(dn.size());
     double max_coord = 0.0;
     {
@@ -490,6 +498,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
             for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { double m = std::fabs((double)v[k][a]); if (m > max_coord && m < 1e30) max_coord = m; }
         }
     }
+    lap("tight bounds");
     const double margin = std::ldexp(max_coord > 0.0 ? max_coord : 1.0, -19);
     if (c->scene.root_ref >= 0 && wide_ref(0) >= 0) {
         struct Cand { int ref; const float* lo; const float* hi; };      // ref: wide leaf (< 0) or binary interior index
@@ -551,6 +560,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
         n4.push_back(DNode4{});
         c->scene.root_ref4 = wide_ref(c->scene.root_ref >= 0 ? 0 : c->scene.root_ref);
     }
+    lap("wide nodes");
     const int stack_capacity = 16 + 48      /* LDS entries + private spill entries of the traversal kernels */;
     if (stack_need_binary > stack_capacity) { set_error("pt_upload_bvh: tree depth %d exceeds the traversal stack of %d entries", stack_need_binary, stack_capacity); return PT_ERR_ARG; }
     c->wide_fits = wide_ok && stack_need_wide <= stack_capacity;
@@ -570,6 +580,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     c->scene.tris = c->d_tris;
     c->n_nodes = dn.size();
     c->have_bvh = true;
+    lap("device copies");
     return PT_OK;
 }
 
@@ -1181,6 +1192,7 @@ int pt_sync(pt_ctx* c)
     HIP_TRY(hipStreamSynchronize(c->stream));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, c->ev0, c->ev1) == hipSuccess) c->totals.last_ms = ms;
+    else (void)hipGetLastError();       // no timed call yet: the events were never recorded; the error must not stick to the next launch check
     return PT_OK;
 }
 

@@ -392,7 +392,11 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         const int n_idle = __popcll(idle_mask);
         if (n_idle == 64 && !more) break;
         const bool do_refill = more && n_idle >= w.refill_lanes;
-        const bool leaf_now = at_leaf && (__popcll(leaf_mask) >= w.leaf_vote || desc_mask == 0ull);
+        // the vote is taken among the lanes that carry a ray: a wave that is running out of rays must not wait for
+        // sixteen of them at leaves
+        const int n_active = 64 - n_idle;
+        const int vote_need = (n_active >> 1) < w.leaf_vote ? ((n_active >> 1) > 1 ? (n_active >> 1) : 1) : w.leaf_vote;
+        const bool leaf_now = at_leaf && (__popcll(leaf_mask) >= vote_need || desc_mask == 0ull);
 #if PT_STAMPS
         st_age++; st_iters++; st_lanes += __popcll(desc_mask); st_leafphases += __any(leaf_now) ? 1 : 0; st_refills += do_refill ? 1 : 0;
         st_leaflanes += __popcll(__ballot(leaf_now)); st_idle += n_idle;
