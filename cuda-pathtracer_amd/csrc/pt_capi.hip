@@ -30,6 +30,29 @@ using namespace ptamd;
         }                                                                                     \
     } while (0)
 
+// Host loops over n independent items in slices, one thread each (at most 16, the CPU share of one GPU on a
+// shared machine; PT_HOST_THREADS overrides), inline when the loop is short. f(first, last, slice index).
+static int host_threads()
+{
+    static const int n = [] {
+        const char* e = getenv("PT_HOST_THREADS");
+        int v = e ? atoi(e) : 0;
+        if (v <= 0) { v = (int)std::thread::hardware_concurrency(); if (v > 16) v = 16; }
+        return v < 1 ? 1 : v;
+    }();
+    return n;
+}
+template <typename F>
+static void par_for(long long n, long long serial_below, F f)
+{
+    const int nt = n < serial_below ? 1 : host_threads();
+    if (nt <= 1) { f(0LL, n, 0); return; }
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back([=, &f] { f(n * t / nt, n * (t + 1) / nt, t); });
+    f(0LL, n / nt, 0);
+    for (std::thread& x : th) x.join();
+}
+
 // Device allocation that is released on every way out of a function.
 struct DevBuf {
     void* p = nullptr;
@@ -427,16 +450,24 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     // until four are present; absorbed binary nodes disappear
     std::vector<DNode4> n4;
     int stack_need_binary = 0, stack_need_wide = 0;
+    // The sweeps below run level by level over the binary tree, each level in parallel: parents have smaller
+    // indices than their children, so one forward pass gives every node's depth.
+    const int nb = c->scene.root_ref >= 0 ? (int)dn.size() : 0;
+    std::vector<int> depth(nb, 0), level_start, by_level(nb);
     {
-        // stack need of the binary walk: one pending sibling per level
-        std::vector<std::pair<int, int>> st;
-        if (c->scene.root_ref >= 0) st.push_back({0, 1});
-        while (!st.empty()) {
-            auto [i, need] = st.back(); st.pop_back();
-            if (need > stack_need_binary) stack_need_binary = need;
-            if (dn[i].left >= 0) st.push_back({dn[i].left, need + 1});
-            if (dn[i].right >= 0) st.push_back({dn[i].right, need + 1});
+        int max_depth = 0;
+        for (int i = 0; i < nb; i++) {
+            const int dch = depth[i] + 1;
+            if (dn[i].left >= 0) depth[dn[i].left] = dch;
+            if (dn[i].right >= 0) depth[dn[i].right] = dch;
+            if (depth[i] > max_depth) max_depth = depth[i];
         }
+        stack_need_binary = nb ? max_depth + 1 : 0;         // one pending sibling per level of the binary walk
+        level_start.assign((size_t)max_depth + 2, 0);
+        for (int i = 0; i < nb; i++) level_start[(size_t)depth[i] + 1]++;
+        for (size_t l = 1; l < level_start.size(); l++) level_start[l] += level_start[l - 1];
+        std::vector<int> cursor(level_start.begin(), level_start.end() - 1);
+        for (int i = 0; i < nb; i++) by_level[(size_t)cursor[depth[i]]++] = i;
     }
     // Leaves of the wide tree: a binary subtree with at most leaf_merge triangles becomes one leaf. Its triangle
     // records are contiguous because subtrees are emitted whole. A wide leaf reference carries its own
@@ -446,22 +477,13 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     auto wide_leaf = [](int first, int count) { return ~(int)((uint32_t)first | ((uint32_t)(count - 1) << 26)); };
     std::vector<int> sub_first(dn.size(), 0), sub_count(dn.size(), 0);
     auto leaf_count = [&](int ref) { return __builtin_bit_cast(int, dt[(size_t)~ref].q1.w); };
-    if (c->scene.root_ref >= 0) {
-        // children have larger indices than their parents: a reverse sweep sees children first
-        for (int i = (int)dn.size() - 1; i >= 0; i--) {
-            int fl, cl, fr, cr;
-            if (dn[i].left < 0) { fl = ~dn[i].left; cl = leaf_count(dn[i].left); } else { fl = sub_first[dn[i].left]; cl = sub_count[dn[i].left]; }
-            if (dn[i].right < 0) { fr = ~dn[i].right; cr = leaf_count(dn[i].right); } else { fr = sub_first[dn[i].right]; cr = sub_count[dn[i].right]; }
-            sub_first[i] = fl < fr ? fl : fr;
-            sub_count[i] = cl + cr;
-        }
-    }
     // A subtree becomes one leaf only where that saves work: its triangles' boxes must overlap so much that their
     // union is no larger (in surface area) than the two halves together, as for the two triangles of a quad. Unrelated
     // neighbours (a soup of small triangles) keep a box and a test each.
     std::vector<char> mergeable(dn.size(), 0);
+    bool big_leaf = false;
     auto wide_ref = [&](int ref) -> int {       // binary reference -> wide reference (interior stays >= 0, to be renumbered)
-        if (ref < 0) { int n = leaf_count(ref); if (n > 16) wide_ok = false; return wide_leaf(~ref, n > 16 ? 16 : n); }
+        if (ref < 0) { int n = leaf_count(ref); if (n > 16) big_leaf = true; return wide_leaf(~ref, n > 16 ? 16 : n); }
         if (mergeable[ref] && sub_count[ref] <= leaf_merge && sub_count[ref] <= 16) return wide_leaf(sub_first[ref], sub_count[ref]);
         return ref;
     };
@@ -469,7 +491,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     // be padded, as the reference builder's are by 0.1 per vertex, BVH_builder.cpp:19-24), and the safety margin the
     // wide boxes get instead: 2^-19 of the largest coordinate, a few times the rounding of the box and triangle tests.
     struct TightBox { float lo[3], hi[3]; };
-    lap("stack need, subtree counts");
+    lap("depths");
     std::vector<TightBox> tight_l(dn.size()), tight_r(dn.size());
     double max_coord = 0.0;
     {
@@ -484,82 +506,142 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
             return b;
         };
         auto join = [](const TightBox& x, const TightBox& y) { TightBox b; for (int a = 0; a < 3; a++) { b.lo[a] = std::fmin(x.lo[a], y.lo[a]); b.hi[a] = std::fmax(x.hi[a], y.hi[a]); } return b; };
-        if (c->scene.root_ref >= 0) {
-            for (int i = (int)dn.size() - 1; i >= 0; i--) {       // children have larger indices than their parents
-                tight_l[i] = dn[i].left < 0 ? leaf_bounds(dn[i].left) : join(tight_l[dn[i].left], tight_r[dn[i].left]);
-                tight_r[i] = dn[i].right < 0 ? leaf_bounds(dn[i].right) : join(tight_l[dn[i].right], tight_r[dn[i].right]);
-                auto half_area = [](const TightBox& b) { double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2]; return x * y + y * z + z * x; };
-                const bool parts_ok = (dn[i].left < 0 || mergeable[dn[i].left]) && (dn[i].right < 0 || mergeable[dn[i].right]);
+        auto half_area = [](const TightBox& b) { double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2]; return x * y + y * z + z * x; };
+        for (int l = (int)level_start.size() - 2; l >= 0; l--) {        // deepest level first: children before parents
+            const int lo = level_start[(size_t)l], hi = level_start[(size_t)l + 1];
+            par_for(hi - lo, 4096, [&](long long q0, long long q1, int) {
+            for (long long q = lo + q0; q < lo + q1; q++) {
+                const int i = by_level[(size_t)q];
+                const int L = dn[i].left, R = dn[i].right;
+                int fl, cl, fr, cr;
+                if (L < 0) { fl = ~L; cl = leaf_count(L); } else { fl = sub_first[L]; cl = sub_count[L]; }
+                if (R < 0) { fr = ~R; cr = leaf_count(R); } else { fr = sub_first[R]; cr = sub_count[R]; }
+                sub_first[i] = fl < fr ? fl : fr;
+                sub_count[i] = cl + cr;
+                tight_l[i] = L < 0 ? leaf_bounds(L) : join(tight_l[L], tight_r[L]);
+                tight_r[i] = R < 0 ? leaf_bounds(R) : join(tight_l[R], tight_r[R]);
+                const bool parts_ok = (L < 0 || mergeable[L]) && (R < 0 || mergeable[R]);
                 mergeable[i] = parts_ok && half_area(join(tight_l[i], tight_r[i])) <= half_area(tight_l[i]) + half_area(tight_r[i]);
             }
+            });
         }
-        for (const pt_triangle& T : c->tris) {
-            const float* v[3] = {&T.a.x, &T.b.x, &T.c.x};
-            for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { double m = std::fabs((double)v[k][a]); if (m > max_coord && m < 1e30) max_coord = m; }
-        }
+        std::vector<double> part_max((size_t)host_threads(), 0.0);
+        par_for((long long)c->tris.size(), 65536, [&](long long t0, long long t1, int slice) {
+            double mx = 0.0;
+            for (long long t = t0; t < t1; t++) {
+                const pt_triangle& T = c->tris[(size_t)t];
+                const float* v[3] = {&T.a.x, &T.b.x, &T.c.x};
+                for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { double m = std::fabs((double)v[k][a]); if (m > mx && m < 1e30) mx = m; }
+            }
+            part_max[(size_t)slice] = mx;
+        });
+        for (double m : part_max) if (m > max_coord) max_coord = m;
     }
     lap("tight bounds");
     const double margin = std::ldexp(max_coord > 0.0 ? max_coord : 1.0, -19);
     if (c->scene.root_ref >= 0 && wide_ref(0) >= 0) {
-        struct Cand { int ref; const float* lo; const float* hi; };      // ref: wide leaf (< 0) or binary interior index
+        // level by level from the root, every node of a level in parallel; the children of a node get consecutive
+        // indices, handed out by a running sum over the level so that the numbering does not depend on thread timing
+        struct Cand { int ref; const float* lo; const float* hi; double area; };      // ref: wide leaf (< 0) or binary interior index
         struct Item { int src, dst, need; };
-        std::vector<Item> st;
+        struct Made { DNode4 d; int kid[4]; int n_kids; int need; };
+        auto area = [](const float* lo, const float* hi) { double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2]; return x * y + y * z + z * x; };
+        std::vector<Item> items, next;
+        std::vector<Made> made;
+        std::vector<int> base;
         n4.push_back(DNode4{});
-        st.push_back(Item{0, 0, 0});
-        auto area = [](const Cand& k) { double x = (double)k.hi[0] - k.lo[0], y = (double)k.hi[1] - k.lo[1], z = (double)k.hi[2] - k.lo[2]; return x * y + y * z + z * x; };
-        while (!st.empty()) {
-            Item it = st.back(); st.pop_back();
-            std::vector<Cand> cand;
-            cand.push_back(Cand{wide_ref(dn[it.src].left), tight_l[it.src].lo, tight_l[it.src].hi});
-            cand.push_back(Cand{wide_ref(dn[it.src].right), tight_r[it.src].lo, tight_r[it.src].hi});
-            while (cand.size() < 4) {
-                int pick = -1; double best = -1.0;
-                for (size_t k = 0; k < cand.size(); k++) if (cand[k].ref >= 0 && area(cand[k]) > best) { best = area(cand[k]); pick = (int)k; }
-                if (pick < 0) break;
-                const int src = cand[pick].ref;
-                cand[pick] = Cand{wide_ref(dn[src].left), tight_l[src].lo, tight_l[src].hi};
-                cand.push_back(Cand{wide_ref(dn[src].right), tight_r[src].lo, tight_r[src].hi});
-            }
-            DNode4 d{};
-            int need = it.need + (int)cand.size() - 1;
-            if (need > stack_need_wide) stack_need_wide = need;
-            // the node's grid: origin at the lowest corner of the widened boxes (rounded down to single precision),
-            // cell = the smallest power of two with which the boxes span at most 255 cells
-            uint32_t exps = 0;
-            for (int a = 0; a < 3; a++) {
-                double lo = INFINITY, hi = -INFINITY;
-                for (const Cand& k : cand) { lo = std::fmin(lo, (double)k.lo[a] - margin); hi = std::fmax(hi, (double)k.hi[a] + margin); }
-                if (!(lo > -1e30 && hi < 1e30)) { wide_ok = false; lo = 0.0; hi = 1.0; }      // non-finite vertices: the binary walk takes the scene
-                float org = (float)lo;
-                if ((double)org > lo) org = std::nextafterf(org, -INFINITY);
-                int e = -126;
-                while (hi - (double)org > 255.0 * std::ldexp(1.0, e) && e < 127) e++;
-                const double cell = std::ldexp(1.0, e);
-                d.w[a] = __builtin_bit_cast(uint32_t, org);
-                exps |= (uint32_t)(uint8_t)(int8_t)e << (8 * a);
-                for (size_t k = 0; k < cand.size(); k++) {
-                    double ql = std::floor(((double)cand[k].lo[a] - margin - (double)org) / cell), qh = std::ceil(((double)cand[k].hi[a] + margin - (double)org) / cell);
-                    ql = ql < 0.0 ? 0.0 : (ql > 255.0 ? 255.0 : ql); qh = qh < 0.0 ? 0.0 : (qh > 255.0 ? 255.0 : qh);
-                    d.w[4 + a] |= (uint32_t)ql << (8 * k);
-                    d.w[7 + a] |= (uint32_t)qh << (8 * k);
+        items.push_back(Item{0, 0, 0});
+        bool bad_box = false;
+        while (!items.empty()) {
+            const long long n_items = (long long)items.size();
+            made.resize(items.size());
+            std::vector<int> part_need((size_t)host_threads(), 0);
+            std::vector<char> part_bad((size_t)host_threads(), 0);
+            par_for(n_items, 2048, [&](long long q0, long long q1, int slice) {
+            int level_need = 0;
+            bool bad_box = false;
+            for (long long q = q0; q < q1; q++) {
+                const Item it = items[(size_t)q];
+                Cand cand[4];
+                int nc = 2;
+                cand[0] = Cand{wide_ref(dn[it.src].left), tight_l[it.src].lo, tight_l[it.src].hi, 0.0};
+                cand[1] = Cand{wide_ref(dn[it.src].right), tight_r[it.src].lo, tight_r[it.src].hi, 0.0};
+                for (int k = 0; k < 2; k++) cand[k].area = area(cand[k].lo, cand[k].hi);
+                while (nc < 4) {
+                    int pick = -1; double best = -1.0;
+                    for (int k = 0; k < nc; k++) if (cand[k].ref >= 0 && cand[k].area > best) { best = cand[k].area; pick = k; }
+                    if (pick < 0) break;
+                    const int src = cand[pick].ref;
+                    cand[pick] = Cand{wide_ref(dn[src].left), tight_l[src].lo, tight_l[src].hi, area(tight_l[src].lo, tight_l[src].hi)};
+                    cand[nc++] = Cand{wide_ref(dn[src].right), tight_r[src].lo, tight_r[src].hi, area(tight_r[src].lo, tight_r[src].hi)};
+                }
+                Made& m = made[(size_t)q];
+                m.d = DNode4{};
+                m.need = it.need + nc - 1;
+                if (m.need > level_need) level_need = m.need;
+                // the node's grid: origin at the lowest corner of the widened boxes (rounded down to single precision),
+                // cell = the smallest power of two with which the boxes span at most 255 cells
+                uint32_t exps = 0;
+                for (int a = 0; a < 3; a++) {
+                    double lo = INFINITY, hi = -INFINITY;
+                    for (int k = 0; k < nc; k++) { lo = std::fmin(lo, (double)cand[k].lo[a] - margin); hi = std::fmax(hi, (double)cand[k].hi[a] + margin); }
+                    if (!(lo > -1e30 && hi < 1e30)) { bad_box = true; lo = 0.0; hi = 1.0; }      // non-finite vertices: the binary walk takes the scene
+                    float org = (float)lo;
+                    if ((double)org > lo) org = std::nextafterf(org, -INFINITY);
+                    int e = 0;
+                    (void)std::frexp((hi - (double)org) / 255.0, &e);        // extent / 255 = f * 2^e with f in [0.5, 1): 2^e is the smallest cell that fits, or one too large
+                    if (e > -126 && hi - (double)org <= 255.0 * std::ldexp(1.0, e - 1)) e--;
+                    e = e < -126 ? -126 : (e > 127 ? 127 : e);
+                    const double cell = std::ldexp(1.0, e);
+                    m.d.w[a] = __builtin_bit_cast(uint32_t, org);
+                    exps |= (uint32_t)(uint8_t)(int8_t)e << (8 * a);
+                    for (int k = 0; k < nc; k++) {
+                        double ql = std::floor(((double)cand[k].lo[a] - margin - (double)org) / cell), qh = std::ceil(((double)cand[k].hi[a] + margin - (double)org) / cell);
+                        ql = ql < 0.0 ? 0.0 : (ql > 255.0 ? 255.0 : ql); qh = qh < 0.0 ? 0.0 : (qh > 255.0 ? 255.0 : qh);
+                        m.d.w[4 + a] |= (uint32_t)ql << (8 * k);
+                        m.d.w[7 + a] |= (uint32_t)qh << (8 * k);
+                    }
+                }
+                m.d.w[3] = exps;
+                m.n_kids = 0;
+                for (int k = 0; k < 4; k++) {
+                    if (k >= nc) { m.d.ref[k] = (int)0x80000000; continue; }
+                    if (cand[k].ref >= 0) { m.kid[m.n_kids++] = cand[k].ref; m.d.ref[k] = 0; }       // numbered below
+                    else m.d.ref[k] = cand[k].ref;
                 }
             }
-            d.w[3] = exps;
-            for (int k = 0; k < 4; k++) {
-                if (k >= (int)cand.size()) { d.ref[k] = (int)0x80000000; continue; }
-                if (cand[k].ref >= 0) {
-                    d.ref[k] = (int)n4.size();
-                    n4.push_back(DNode4{});
-                    st.push_back(Item{cand[k].ref, d.ref[k], need});
-                } else d.ref[k] = cand[k].ref;
+            part_need[(size_t)slice] = level_need; part_bad[(size_t)slice] = bad_box ? 1 : 0;
+            });
+            for (int v : part_need) if (v > stack_need_wide) stack_need_wide = v;
+            for (char v : part_bad) if (v) bad_box = true;
+            base.resize(items.size());
+            int total_kids = 0;
+            for (size_t q = 0; q < items.size(); q++) { base[q] = (int)n4.size() + total_kids; total_kids += made[q].n_kids; }
+            const size_t first_new = n4.size();
+            n4.resize(first_new + (size_t)total_kids);
+            next.resize((size_t)total_kids);
+            par_for(n_items, 2048, [&](long long q0, long long q1, int) {
+            for (long long q = q0; q < q1; q++) {
+                Made& m = made[(size_t)q];
+                int j = 0;
+                for (int k = 0; k < 4; k++) {
+                    if (m.d.ref[k] != 0 || j >= m.n_kids) continue;        // interior children were marked 0 (no other reference is 0: leaves are negative)
+                    m.d.ref[k] = base[(size_t)q] + j;
+                    next[(size_t)(base[(size_t)q] - (int)first_new + j)] = Item{m.kid[j], base[(size_t)q] + j, m.need};
+                    j++;
+                }
+                n4[(size_t)items[(size_t)q].dst] = m.d;
             }
-            n4[it.dst] = d;
+            });
+            items.swap(next);
         }
+        if (bad_box) wide_ok = false;
         c->scene.root_ref4 = 0;
     } else {
         n4.push_back(DNode4{});
         c->scene.root_ref4 = wide_ref(c->scene.root_ref >= 0 ? 0 : c->scene.root_ref);
     }
+    if (big_leaf) wide_ok = false;
     lap("wide nodes");
     const int stack_capacity = 16 + 48      /* LDS entries + private spill entries of the traversal kernels */;
     if (stack_need_binary > stack_capacity) { set_error("pt_upload_bvh: tree depth %d exceeds the traversal stack of %d entries", stack_need_binary, stack_capacity); return PT_ERR_ARG; }
