@@ -108,7 +108,7 @@ struct pt_ctx {
     int mode = PT_MODE_WAVEFRONT;
     int pool_slots = 1 << 24;
     int chunk_frames = 512;         // frames per staging chunk: every chunk pays one ramp-up and one run-down of the pool
-    int refill_lanes = 12, leaf_vote = 16, n_cus = 256;
+    int refill_lanes = 8, leaf_vote = 24, n_cus = 256;
     int extend_blocks_per_cu = 0;   // 0: 5 when one lane runs (all the LDS), 3 when two do
     // The wavefront loop runs as up to two independent lanes, each with its own slot pool, staging array,
     // counters and stream, on disjoint pixels (alternate blocks of 64): while one lane's traversal kernel (ALU bound)

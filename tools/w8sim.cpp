@@ -75,6 +75,7 @@ static int count_tris(const Tree& T, int ref, int limit)
 // quant: 0 fp32 boxes, 1: 16-bit global grid (+2 cells), 2: 8-bit local grid on top of the 16-bit global one
 struct Quant { int mode; double org[3], cell[3]; };
 static double g_pad = 0.003;
+static double g_levels = 255.0;
 static void quantize_node(WNode& n, const Quant& Q)
 {
     if (Q.mode == 0) return;
@@ -84,11 +85,11 @@ static void quantize_node(WNode& n, const Quant& Q)
             for (int k = 0; k < n.n; k++) { o = std::min(o, (double)n.c[k].box.lo[a] - g_pad); m = std::max(m, (double)n.c[k].box.hi[a] + g_pad); }
             float of = (float)o; if ((double)of > o) of = std::nextafterf(of, -1e30f);
             int e = -40;
-            while ((m - of) > 255.0 * std::ldexp(1.0, e)) e++;
+            while ((m - of) > g_levels * std::ldexp(1.0, e)) e++;
             double cell = std::ldexp(1.0, e);
             for (int k = 0; k < n.n; k++) {
                 double ql = std::floor(((double)n.c[k].box.lo[a] - g_pad - of) / cell), qh = std::ceil(((double)n.c[k].box.hi[a] + g_pad - of) / cell);
-                ql = std::max(0.0, ql); qh = std::min(255.0, qh);
+                ql = std::max(0.0, ql); qh = std::min(g_levels, qh);
                 n.c[k].box.lo[a] = (float)(of + ql * cell); n.c[k].box.hi[a] = (float)(of + qh * cell);
             }
         }
@@ -267,6 +268,7 @@ static void trace(const Wide& Wd, const Tree& T, const float o[3], const float d
 extern "C" int w8sim(const pt_triangle* tris, int ntri, const pt_bvh_node* nodes, const int* idx, const float* rays, int nrays,
                      int W, int leaf_merge, int quant, int octant_slots, int policy, double* out /* steps, tris, stale, pushes, maxsp, nodes, mismatches */)
 {
+    g_levels = quant >= 100 ? std::ldexp(1.0, quant / 100) - 1.0 : 255.0; quant %= 100;
     g_tight = quant >= 10; quant %= 10;
     Tree T; T.tris = tris; T.ntri = ntri;
     T.tribox.resize(ntri);

@@ -45,11 +45,12 @@ def run(W, merge, quant, octs, policy):
     L.w8sim(tris.ctypes.data_as(C.c_void_p), C.c_int(len(tris)), nodes.ctypes.data_as(C.c_void_p), idx.ctypes.data_as(C.c_void_p),
             flat.ctypes.data_as(C.c_void_p), C.c_int(len(flat)), C.c_int(W), C.c_int(merge), C.c_int(quant), C.c_int(octs), C.c_int(policy), out)
     print('W%d merge%d quant%d oct%d policy%d: steps %.2f tris %.2f stale %.2f pushes %.2f maxsp %d nodes %d longest %d' % (W, merge, quant, octs, policy, out[0], out[1], out[2], out[3], out[4], out[5], out[7]), flush=True)
-run(4, 2, 1, 0, 0)      # the present scheme
-run(4, 2, 11, 0, 0)     # the same on tight boxes recomputed from the triangles
-run(4, 2, 0, 0, 0)      # fp32 boxes as given
+run(4, 2, 13, 0, 0)     # local 8-bit frames on tight boxes
+run(4, 2, 613, 0, 0)    # 6 bits
+run(4, 2, 1013, 0, 0)   # 10 bits
+run(4, 2, 1213, 0, 0)   # 12 bits
+run(4, 2, 1613, 0, 0)   # 16 bits
 run(4, 2, 10, 0, 0)     # fp32 tight boxes
-run(4, 2, 13, 0, 0)     # local 8-bit frames on tight boxes, pad 0.003
-run(4, 1, 13, 0, 0)
-run(4, 3, 13, 0, 0)
-run(8, 1, 13, 0, 0)
+run(6, 2, 13, 0, 0)
+run(8, 2, 13, 0, 0)
+run(8, 2, 1613, 0, 0)
