@@ -328,14 +328,19 @@ PT_DEV void wide_step(const float4& n0, const float4& n1, const float4& n2, cons
     const uint32_t lx = __float_as_uint(n1.x), ly = __float_as_uint(n1.y), lz = __float_as_uint(n1.z);
     const uint32_t hx = __float_as_uint(n1.w), hy = __float_as_uint(n2.x), hz = __float_as_uint(n2.y);
     r0 = __float_as_int(n3.x); r1 = __float_as_int(n3.y); r2 = __float_as_int(n3.z); r3 = __float_as_int(n3.w);
+    // the near plane of a slab is its low one for a direction component >= 0, its high one otherwise (the plane
+    // distance is monotonic in the cell coordinate): choosing the words once per node replaces a min and a max per
+    // child and axis, with bit-identical results
+    const bool ngx = inv.x < 0.f, ngy = inv.y < 0.f, ngz = inv.z < 0.f;
+    const uint32_t ax = ngx ? hx : lx, fx = ngx ? lx : hx, ay = ngy ? hy : ly, fy = ngy ? ly : hy, az = ngz ? hz : lz, fz = ngz ? lz : hz;
     float dk[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        float t0x = __builtin_fmaf((float)((lx >> (8 * k)) & 255u), sx, bx), t1x = __builtin_fmaf((float)((hx >> (8 * k)) & 255u), sx, bx);
-        float t0y = __builtin_fmaf((float)((ly >> (8 * k)) & 255u), sy, by), t1y = __builtin_fmaf((float)((hy >> (8 * k)) & 255u), sy, by);
-        float t0z = __builtin_fmaf((float)((lz >> (8 * k)) & 255u), sz, bz), t1z = __builtin_fmaf((float)((hz >> (8 * k)) & 255u), sz, bz);
-        float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)), __builtin_fminf(t0z, t1z));
-        float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)), __builtin_fmaxf(t0z, t1z));
+        const float tnx = __builtin_fmaf((float)((ax >> (8 * k)) & 255u), sx, bx), tfx = __builtin_fmaf((float)((fx >> (8 * k)) & 255u), sx, bx);
+        const float tny = __builtin_fmaf((float)((ay >> (8 * k)) & 255u), sy, by), tfy = __builtin_fmaf((float)((fy >> (8 * k)) & 255u), sy, by);
+        const float tnz = __builtin_fmaf((float)((az >> (8 * k)) & 255u), sz, bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 255u), sz, bz);
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
+        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
         dk[k] = (tf > tn && tf > 0.f && tn < cull) ? tn : 1e30f;
     }
     d0 = r0 == PT_TRAV_EMPTY ? 1e30f : dk[0]; d1 = r1 == PT_TRAV_EMPTY ? 1e30f : dk[1];

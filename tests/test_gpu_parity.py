@@ -648,6 +648,7 @@ def test_group_of_one_gpu_and_group_errors():
     r.close(); r2.close()
 
 
+@pytest.mark.timeout(600)      # three bench processes, each importing torch afresh
 def test_bench_two_ranks_on_one_gpu_match_one_rank():
     """bench.py itself under torch.distributed.run with two ranks sharing the GPU (gloo backend; RCCL needs one GPU per
     rank): the sample partition, the reduce onto rank 0 and the JSON line. With a fixed total sample count (strong
