@@ -601,6 +601,9 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
                         m.d.w[4 + a] |= (uint32_t)ql << (8 * k);
                         m.d.w[7 + a] |= (uint32_t)qh << (8 * k);
                     }
+                    // a child that does not exist gets an inverted slab (low plane 255, high plane 0): its exit never
+                    // lies beyond its entry, so the walk drops it without looking at its reference
+                    for (int k = nc; k < 4; k++) m.d.w[4 + a] |= 255u << (8 * k);
                 }
                 m.d.w[3] = exps;
                 m.n_kids = 0;

@@ -343,8 +343,7 @@ PT_DEV void wide_step(const float4& n0, const float4& n1, const float4& n2, cons
         const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
         dk[k] = (tf > tn && tf > 0.f && tn < cull) ? tn : 1e30f;
     }
-    d0 = r0 == PT_TRAV_EMPTY ? 1e30f : dk[0]; d1 = r1 == PT_TRAV_EMPTY ? 1e30f : dk[1];
-    d2 = r2 == PT_TRAV_EMPTY ? 1e30f : dk[2]; d3 = r3 == PT_TRAV_EMPTY ? 1e30f : dk[3];
+    d0 = dk[0]; d1 = dk[1]; d2 = dk[2]; d3 = dk[3];       // (a missing child's slabs are inverted: never entered)
     auto cswap = [](float& da, int& ra, float& db, int& rb) {
         bool sw = db < da;
         float td = sw ? db : da; int tr = sw ? rb : ra;

@@ -41,7 +41,7 @@ static_assert(sizeof(DNodeQ) == 32, "compact node must be 32 bytes");
 // do not depend on them, only the number of nodes visited does.
 struct __attribute__((aligned(64))) DNode4 {
     uint32_t w[12];       // w[0..2]: origin x, y, z (float bits); w[3]: log2 of the cell size per axis, one signed byte each (x | y << 8 | z << 16);
-                          // w[4..9]: byte k of each word belongs to child k: min.x, min.y, min.z, max.x, max.y, max.z in cells from the origin; w[10..11]: 0
+                          // w[4..9]: byte k of each word belongs to child k: min.x, min.y, min.z, max.x, max.y, max.z in cells from the origin (a missing child: min 255, max 0, never entered); w[10..11]: 0
     int ref[4];           // as DNode
 };
 static_assert(sizeof(DNode4) == 64, "wide node must be 64 bytes");

@@ -487,8 +487,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                 const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
                 dk[k] = (tf > tn && tf > 0.f && tn < cull) ? tn : 1e30f;
             }
-            float d0 = r0 == PT_TRAV_EMPTY ? 1e30f : dk[0], d1 = r1 == PT_TRAV_EMPTY ? 1e30f : dk[1];
-            float d2 = r2 == PT_TRAV_EMPTY ? 1e30f : dk[2], d3 = r3 == PT_TRAV_EMPTY ? 1e30f : dk[3];
+            float d0 = dk[0], d1 = dk[1], d2 = dk[2], d3 = dk[3];       // (a missing child's slabs are inverted: never entered)
             auto cswap = [](float& da, int& ra, float& db, int& rb) {
                 bool sw = db < da;
                 float td = sw ? db : da; int tr = sw ? rb : ra;
