@@ -103,7 +103,7 @@ struct pt_ctx {
     int counting = 0;               // 0 off, 1 the reference-order walk, 2 the production walk's own work
     DCounters* d_ctr = nullptr;
     pt_counters totals{};
-    size_t n_nodes = 0;
+    size_t n_nodes = 0, n_nodes4 = 0;
     // wavefront pool
     int mode = PT_MODE_WAVEFRONT;
     int pool_slots = 1 << 24;
@@ -664,6 +664,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     c->scene.nodes = c->d_nodes;
     c->scene.tris = c->d_tris;
     c->n_nodes = dn.size();
+    c->n_nodes4 = n4.size();
     c->have_bvh = true;
     lap("device copies");
     return PT_OK;
@@ -672,21 +673,49 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
 int pt_build_bvh(pt_ctx* c, int flavour)
 {
     if (!c || !c->have_tris) { set_error("pt_build_bvh: upload triangles first"); return PT_ERR_STATE; }
-    if (flavour != PT_BVH_REFERENCE && flavour != PT_BVH_GPU_LBVH) { set_error("pt_build_bvh: unknown flavour %d", flavour); return PT_ERR_ARG; }
+    if (flavour != PT_BVH_REFERENCE && flavour != PT_BVH_GPU_LBVH && flavour != PT_BVH_GPU_LBVH_VIA_HOST) { set_error("pt_build_bvh: unknown flavour %d", flavour); return PT_ERR_ARG; }
     int n = (int)c->tris.size();
-    std::vector<pt_bvh_node> nodes((size_t)2 * n - 1 + 1);
-    if (flavour == PT_BVH_GPU_LBVH) {
+    if (flavour == PT_BVH_GPU_LBVH && n >= 64 && (size_t)n < ((size_t)1 << 26)) {
+        // tree and traversal layouts are made on the device; the host receives the leaf order and a few numbers
+        c->epoch++;
         HIP_TRY(hipSetDevice(c->device));
-        pt_bvh_node* d_nodes = nullptr;
-        int* d_idx = nullptr;
-        HIP_TRY(hipMalloc((void**)&d_nodes, ((size_t)2 * n - 1) * sizeof(pt_bvh_node)));
-        if (hipMalloc((void**)&d_idx, (size_t)n * sizeof(int)) != hipSuccess) { (void)hipFree(d_nodes); set_error("pt_build_bvh: out of device memory"); return PT_ERR_NOMEM; }
-        int rc = gpu_build_lbvh(c->d_tri_ref, n, d_nodes, d_idx, c->stream);
-        if (rc == PT_OK && hipMemcpy(nodes.data(), d_nodes, ((size_t)2 * n - 1) * sizeof(pt_bvh_node), hipMemcpyDeviceToHost) != hipSuccess) { set_error("pt_build_bvh: copy failed"); rc = PT_ERR_HIP; }
         std::vector<int> new_idx((size_t)n);
-        if (rc == PT_OK && hipMemcpy(new_idx.data(), d_idx, (size_t)n * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) { set_error("pt_build_bvh: copy failed"); rc = PT_ERR_HIP; }
-        (void)hipFree(d_nodes); (void)hipFree(d_idx);
+        GpuScene g;
+        int rc = gpu_build_scene(c->d_tri_ref, n, c->leaf_merge, &g, new_idx.data(), c->stream);
         if (rc != PT_OK) return rc;
+        const int stack_capacity = 16 + 48      /* LDS entries + private spill entries of the traversal kernels */;
+        if (g.stack_need_binary > stack_capacity) {
+            (void)hipFree(g.nodes); (void)hipFree(g.qnodes); (void)hipFree(g.nodes4); (void)hipFree(g.tris);
+            set_error("pt_build_bvh: tree depth %d exceeds the traversal stack of %d entries", g.stack_need_binary, stack_capacity);
+            return PT_ERR_ARG;
+        }
+        free_scene_geometry(c);
+        c->tri_idx.swap(new_idx);
+        c->d_nodes = g.nodes; c->d_qnodes = g.qnodes; c->d_nodes4 = g.nodes4; c->d_tris = g.tris;
+        c->scene.nodes = g.nodes; c->scene.qnodes = g.qnodes; c->scene.nodes4 = g.nodes4; c->scene.tris = g.tris;
+        c->scene.root_ref = 0; c->scene.root_ref4 = 0;
+        for (int a = 0; a < 3; a++) {
+            c->scene.root_min[a] = g.root_min[a]; c->scene.root_max[a] = g.root_max[a];
+            c->scene.q_origin[a] = g.q_origin[a]; c->scene.q_cell[a] = g.q_cell[a]; c->scene.q_inv_cell[a] = g.q_inv_cell[a];
+        }
+        c->wide_fits = !g.bad_box && g.stack_need_wide <= stack_capacity;
+        c->scene.wide = (c->wide_fits && c->node_width == 4) ? 1 : 0;
+        c->n_nodes = g.n_nodes; c->n_nodes4 = g.n_nodes4;
+        c->have_bvh = true;
+        return PT_OK;
+    }
+    std::vector<pt_bvh_node> nodes((size_t)2 * n - 1 + 1);
+    if (flavour != PT_BVH_REFERENCE) {
+        // the device-built tree in the reference's node layout, taken in like an uploaded one
+        HIP_TRY(hipSetDevice(c->device));
+        DevBuf d_nodes, d_idx;
+        HIP_TRY(d_nodes.alloc(((size_t)2 * n - 1) * sizeof(pt_bvh_node)));
+        HIP_TRY(d_idx.alloc((size_t)n * sizeof(int)));
+        int rc = gpu_build_lbvh(c->d_tri_ref, n, d_nodes.as<pt_bvh_node>(), d_idx.as<int>(), c->stream);
+        if (rc != PT_OK) return rc;
+        std::vector<int> new_idx((size_t)n);
+        HIP_TRY(hipMemcpy(nodes.data(), d_nodes.p, ((size_t)2 * n - 1) * sizeof(pt_bvh_node), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(new_idx.data(), d_idx.p, (size_t)n * sizeof(int), hipMemcpyDeviceToHost));
         for (int i = 0; i < n; i++) if (new_idx[i] < 0 || new_idx[i] >= n) { set_error("pt_build_bvh: the device build returned a bad index"); return PT_ERR_HIP; }
         // the index array and the device tree change together or not at all
         c->tri_idx.swap(new_idx);
@@ -1543,7 +1572,8 @@ int pt_reset_counters(pt_ctx* c)
 int pt_scene_bytes(pt_ctx* c, uint64_t* node_bytes, uint64_t* tri_bytes)
 {
     if (!c || !c->have_bvh) { set_error("pt_scene_bytes: no BVH"); return PT_ERR_STATE; }
-    if (node_bytes) *node_bytes = c->n_nodes * sizeof(DNode);
+    // the nodes the production traversal walks: 4-wide, or the quantized binary ones
+    if (node_bytes) *node_bytes = c->scene.wide ? c->n_nodes4 * sizeof(DNode4) : c->n_nodes * sizeof(DNodeQ);
     if (tri_bytes) *tri_bytes = c->tris.size() * sizeof(DTri);
     return PT_OK;
 }

@@ -1,6 +1,8 @@
-// BVH build on the GPU: a linear BVH (Morton order + the radix-tree construction of Karras 2012) written in
-// the reference's node layout (structs.cuh:130-137), so that it enters the library through the same upload
-// path as a tree from BVH_builder.cpp. The reference has no counterpart: its builder is a host loop of
+// BVH build on the GPU: a linear BVH (Morton order + the radix-tree construction of Karras 2012). Two outputs:
+// gpu_build_scene leaves the traversal layouts themselves in device memory (binary nodes in breadth-first order,
+// their quantized twins, leaf-ordered triangle records, 4-wide nodes; nothing but a few counters returns to the
+// host), and gpu_build_lbvh writes the reference's node layout (structs.cuh:130-137), so that the same tree can enter
+// the library through the upload path of a tree from BVH_builder.cpp (kept as the cross-check of the first). The reference has no counterpart: its builder is a host loop of
 // O(297 * n * depth). Closest hits do not depend on the tree (every triangle is tested against the same
 // rule), so a render with this tree gives the same image; only the traversal cost and the test counters differ.
 //
@@ -10,7 +12,10 @@
 // padding of 0.1 per vertex (BVH_builder.cpp:19-24): the box test rejects boxes of zero thickness.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <cmath>
 #include <cstdint>
+#include <cstring>
+#include <vector>
 #include "pt_internal.h"
 #include "pt_launch.h"
 
@@ -86,7 +91,8 @@ __device__ inline int prefix(const uint64_t* __restrict__ keys, int n, int i, in
 
 // radix-tree node j (0 <= j < n-1): its children (>= 0: internal node, < 0: ~leaf) and the parent links
 __global__ __launch_bounds__(256) void gb_radix_tree(const uint64_t* __restrict__ keys, int n, int* __restrict__ left, int* __restrict__ right,
-                                                     int* __restrict__ parent_of_internal, int* __restrict__ parent_of_leaf)
+                                                     int* __restrict__ parent_of_internal, int* __restrict__ parent_of_leaf,
+                                                     int* __restrict__ range_first, int* __restrict__ range_count)
 {
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n - 1) return;
@@ -108,6 +114,8 @@ __global__ __launch_bounds__(256) void gb_radix_tree(const uint64_t* __restrict_
     int cl = lo == gamma ? ~gamma : gamma;
     int cr = hi == gamma + 1 ? ~(gamma + 1) : gamma + 1;
     left[i] = cl; right[i] = cr;
+    if (range_first) { range_first[i] = lo; range_count[i] = hi - lo + 1; }      // the leaves below: sorted positions [lo, hi]
+    if (!parent_of_internal) return;
     // a child learns its parent and on which side it hangs: bit 0 = right side
     if (cl >= 0) parent_of_internal[cl] = i << 1; else parent_of_leaf[~cl] = i << 1;
     if (cr >= 0) parent_of_internal[cr] = i << 1 | 1; else parent_of_leaf[~cr] = i << 1 | 1;
@@ -148,6 +156,222 @@ __global__ __launch_bounds__(256) void gb_refit(const pt_triangle* __restrict__ 
     }
 }
 
+// ---------------------------------------------------------------- traversal layouts, built on the device
+// The radix tree is renumbered breadth first (node 0 = root, the interior children of consecutive nodes are
+// consecutive): the bottom-up pass then runs level by level over contiguous nodes with plain stores, no atomics.
+
+struct TightBox { float lo[3], hi[3]; };
+struct NodeAux { int first, count, height, mergeable; };     // leaves below (sorted positions), levels below, "may become one leaf"
+
+// interior children of the nodes of one level: 0, 1 or 2 each
+__global__ __launch_bounds__(256) void gb_bfs_count(const int* __restrict__ order, int lo, int cnt, const int* __restrict__ left, const int* __restrict__ right, int* __restrict__ kids)
+{
+    int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= cnt) return;
+    int r = order[lo + q];
+    kids[q] = (left[r] >= 0 ? 1 : 0) + (right[r] >= 0 ? 1 : 0);
+}
+
+// the next level: children in the order of their parents, left before right; off = exclusive running sum of kids
+__global__ __launch_bounds__(256) void gb_bfs_emit(int* __restrict__ order, int lo, int cnt, const int* __restrict__ left, const int* __restrict__ right,
+                                                   const int* __restrict__ off, int* __restrict__ newid)
+{
+    int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= cnt) return;
+    int r = order[lo + q];
+    int at = lo + cnt + off[q];
+    int l = left[r], rr = right[r];
+    if (l >= 0) { order[at] = l; newid[l] = at; at++; }
+    if (rr >= 0) { order[at] = rr; newid[rr] = at; }
+}
+
+__device__ inline TightBox tri_bounds(const pt_triangle& t)
+{
+    TightBox b;
+    b.lo[0] = fminf(fminf(t.a.x, t.b.x), t.c.x); b.lo[1] = fminf(fminf(t.a.y, t.b.y), t.c.y); b.lo[2] = fminf(fminf(t.a.z, t.b.z), t.c.z);
+    b.hi[0] = fmaxf(fmaxf(t.a.x, t.b.x), t.c.x); b.hi[1] = fmaxf(fmaxf(t.a.y, t.b.y), t.c.y); b.hi[2] = fmaxf(fmaxf(t.a.z, t.b.z), t.c.z);
+    return b;
+}
+__device__ inline TightBox join(const TightBox& x, const TightBox& y)
+{
+    TightBox b;
+    for (int a = 0; a < 3; a++) { b.lo[a] = fminf(x.lo[a], y.lo[a]); b.hi[a] = fmaxf(x.hi[a], y.hi[a]); }
+    return b;
+}
+__device__ inline double half_area(const float* lo, const float* hi)
+{
+    double x = (double)hi[0] - lo[0], y = (double)hi[1] - lo[1], z = (double)hi[2] - lo[2];
+    return x * y + y * z + z * x;
+}
+
+// One level of the bottom-up pass (deepest level first). Node at breadth-first position p: the tight bounds of
+// the triangles below each child, the binary node with the reference's padded boxes (0.1 per side,
+// BVH_builder.cpp:19-24; padding commutes with the union), the range of leaves, the height, and whether the
+// subtree may be tested as one leaf (its union is no larger in surface than its halves together, recursively).
+__global__ __launch_bounds__(256) void gb_fit_level(const pt_triangle* __restrict__ tris, const uint32_t* __restrict__ ids, const int* __restrict__ order,
+                                                    const int* __restrict__ newid, const int* __restrict__ left, const int* __restrict__ right,
+                                                    int lo, int cnt, DNode* __restrict__ nodes, TightBox* __restrict__ tight_l, TightBox* __restrict__ tight_r,
+                                                    NodeAux* __restrict__ aux)
+{
+    int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= cnt) return;
+    const int p = lo + q;
+    const int r = order[p];
+    const int L = left[r], R = right[r];
+    TightBox bl, br;
+    int fl, cl, hl, ml, fr, cr, hr, mr, refl, refr;
+    if (L < 0) { fl = ~L; cl = 1; hl = 0; ml = 1; bl = tri_bounds(tris[ids[fl]]); refl = L; }
+    else { const int c = newid[L]; const NodeAux a = aux[c]; fl = a.first; cl = a.count; hl = a.height; ml = a.mergeable; bl = join(tight_l[c], tight_r[c]); refl = c; }
+    if (R < 0) { fr = ~R; cr = 1; hr = 0; mr = 1; br = tri_bounds(tris[ids[fr]]); refr = R; }
+    else { const int c = newid[R]; const NodeAux a = aux[c]; fr = a.first; cr = a.count; hr = a.height; mr = a.mergeable; br = join(tight_l[c], tight_r[c]); refr = c; }
+    tight_l[p] = bl; tight_r[p] = br;
+    const TightBox u = join(bl, br);
+    NodeAux me;
+    me.first = fl < fr ? fl : fr; me.count = cl + cr; me.height = 1 + (hl > hr ? hl : hr);
+    me.mergeable = (ml && mr && half_area(u.lo, u.hi) <= half_area(bl.lo, bl.hi) + half_area(br.lo, br.hi)) ? 1 : 0;
+    aux[p] = me;
+    DNode d;
+    for (int a = 0; a < 3; a++) { d.lmin[a] = bl.lo[a] - kPad; d.lmax[a] = bl.hi[a] + kPad; d.rmin[a] = br.lo[a] - kPad; d.rmax[a] = br.hi[a] + kPad; }
+    d.left = refl; d.right = refr; d.pad0 = 0; d.pad1 = 0;
+    nodes[p] = d;
+}
+
+// leaf-ordered triangle records (one triangle per leaf) and the index array in the same order
+__global__ __launch_bounds__(256) void gb_emit_tris(const pt_triangle* __restrict__ tris, const uint32_t* __restrict__ ids, int n, DTri* __restrict__ out,
+                                                    int* __restrict__ tri_idx, uint32_t* __restrict__ max_coord_bits)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    float m = 0.f;
+    if (i < n) {
+        const uint32_t id = ids[i];
+        const pt_triangle& T = tris[id];
+        DTri r;
+        r.q0 = make_float4(T.a.x, T.a.y, T.a.z, __uint_as_float(id));
+        r.q1 = make_float4(T.b.x - T.a.x, T.b.y - T.a.y, T.b.z - T.a.z, __int_as_float(1));
+        r.q2 = make_float4(T.c.x - T.a.x, T.c.y - T.a.y, T.c.z - T.a.z, 0.f);
+        out[i] = r;
+        tri_idx[i] = (int)id;
+        const float v[9] = {T.a.x, T.a.y, T.a.z, T.b.x, T.b.y, T.b.z, T.c.x, T.c.y, T.c.z};
+        for (int k = 0; k < 9; k++) { float a = fabsf(v[k]); if (a > m && a < 1e30f) m = a; }
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_down(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(max_coord_bits, __float_as_uint(m));      // non-negative floats order as integers
+}
+
+struct QuantGrid { float origin[3], cell[3]; };
+
+// the binary nodes on the global 16-bit grid, two cells of padding (the fallback walk of the production kernel)
+__global__ __launch_bounds__(256) void gb_quantize(const DNode* __restrict__ nodes, int n_nodes, QuantGrid g, DNodeQ* __restrict__ out)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_nodes) return;
+    const DNode s = nodes[i];
+    DNodeQ t;
+    for (int a = 0; a < 3; a++) {
+        const double o = (double)g.origin[a], c = (double)g.cell[a];
+        auto qlo = [&](float v) { double q = floor(((double)v - o) / c) - 2.0; return (uint16_t)(q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q)); };
+        auto qhi = [&](float v) { double q = ceil(((double)v - o) / c) + 2.0; return (uint16_t)(q < 0.0 ? 0.0 : (q > 65535.0 ? 65535.0 : q)); };
+        t.q[a] = qlo(s.lmin[a]); t.q[3 + a] = qhi(s.lmax[a]); t.q[6 + a] = qlo(s.rmin[a]); t.q[9 + a] = qhi(s.rmax[a]);
+    }
+    t.left = s.left; t.right = s.right;
+    out[i] = t;
+}
+
+// ---- 4-wide nodes, level by level from the root. An item = (binary node to collapse, wide node to write, stack
+// entries a walk may hold when it arrives there).
+__device__ inline int wide_leaf_ref(int first, int count) { return ~(int)((uint32_t)first | ((uint32_t)(count - 1) << 26)); }
+
+// binary reference -> wide reference: a leaf, a subtree that becomes one leaf, or the binary node itself (>= 0)
+__device__ inline int wide_ref_of(int ref, const NodeAux* __restrict__ aux, int leaf_merge)
+{
+    if (ref < 0) return wide_leaf_ref(~ref, 1);
+    const NodeAux a = aux[ref];
+    if (a.mergeable && a.count <= leaf_merge && a.count <= 16) return wide_leaf_ref(a.first, a.count);
+    return ref;
+}
+
+// Writes the wide node of every item with its interior children still as binary node numbers (>= 0) and counts them.
+__global__ __launch_bounds__(256) void gb_wide_make(const int* __restrict__ it_src, const int* __restrict__ it_dst, const int* __restrict__ it_need, int cnt,
+                                                    const DNode* __restrict__ nodes, const TightBox* __restrict__ tight_l, const TightBox* __restrict__ tight_r,
+                                                    const NodeAux* __restrict__ aux, int leaf_merge, double margin, DNode4* __restrict__ n4,
+                                                    int* __restrict__ kids, int* __restrict__ node_need, int* __restrict__ flags /* [0] max need, [1] bad box */)
+{
+    int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= cnt) return;
+    const int src = it_src[q];
+    int ref[4]; TightBox box[4]; double area[4];
+    int nc = 2;
+    ref[0] = wide_ref_of(nodes[src].left, aux, leaf_merge); box[0] = tight_l[src];
+    ref[1] = wide_ref_of(nodes[src].right, aux, leaf_merge); box[1] = tight_r[src];
+    area[0] = half_area(box[0].lo, box[0].hi); area[1] = half_area(box[1].lo, box[1].hi);
+    while (nc < 4) {
+        int pick = -1; double best = -1.0;
+        for (int k = 0; k < nc; k++) if (ref[k] >= 0 && area[k] > best) { best = area[k]; pick = k; }
+        if (pick < 0) break;
+        const int s2 = ref[pick];
+        ref[pick] = wide_ref_of(nodes[s2].left, aux, leaf_merge); box[pick] = tight_l[s2]; area[pick] = half_area(box[pick].lo, box[pick].hi);
+        ref[nc] = wide_ref_of(nodes[s2].right, aux, leaf_merge); box[nc] = tight_r[s2]; area[nc] = half_area(box[nc].lo, box[nc].hi);
+        nc++;
+    }
+    DNode4 d;
+    for (int k = 0; k < 12; k++) d.w[k] = 0u;
+    const int need = it_need[q] + nc - 1;
+    // the node's grid: origin at the lowest corner of the widened boxes (rounded down to single precision),
+    // cell = the smallest power of two with which the boxes span at most 255 cells
+    uint32_t exps = 0;
+    bool bad = false;
+    for (int a = 0; a < 3; a++) {
+        double lo = INFINITY, hi = -INFINITY;
+        for (int k = 0; k < nc; k++) { lo = fmin(lo, (double)box[k].lo[a] - margin); hi = fmax(hi, (double)box[k].hi[a] + margin); }
+        if (!(lo > -1e30 && hi < 1e30)) { bad = true; lo = 0.0; hi = 1.0; }
+        float org = (float)lo;
+        if ((double)org > lo) org = nextafterf(org, -INFINITY);
+        int e = 0;
+        (void)frexp((hi - (double)org) / 255.0, &e);
+        if (e > -126 && hi - (double)org <= 255.0 * ldexp(1.0, e - 1)) e--;
+        e = e < -126 ? -126 : (e > 127 ? 127 : e);
+        const double cell = ldexp(1.0, e);
+        d.w[a] = __float_as_uint(org);
+        exps |= (uint32_t)(uint8_t)(int8_t)e << (8 * a);
+        for (int k = 0; k < nc; k++) {
+            double ql = floor(((double)box[k].lo[a] - margin - (double)org) / cell), qh = ceil(((double)box[k].hi[a] + margin - (double)org) / cell);
+            ql = ql < 0.0 ? 0.0 : (ql > 255.0 ? 255.0 : ql); qh = qh < 0.0 ? 0.0 : (qh > 255.0 ? 255.0 : qh);
+            d.w[4 + a] |= (uint32_t)ql << (8 * k);
+            d.w[7 + a] |= (uint32_t)qh << (8 * k);
+        }
+        for (int k = nc; k < 4; k++) d.w[4 + a] |= 255u << (8 * k);      // a child that does not exist: inverted slab, never entered
+    }
+    d.w[3] = exps;
+    int nk = 0;
+    for (int k = 0; k < 4; k++) {
+        if (k >= nc) { d.ref[k] = (int)0x80000000; continue; }
+        d.ref[k] = ref[k];
+        if (ref[k] >= 0) nk++;
+    }
+    n4[it_dst[q]] = d;
+    kids[q] = nk;
+    node_need[q] = need;
+    atomicMax(&flags[0], need);
+    if (bad) flags[1] = 1;
+}
+
+// Numbers the interior children (consecutive per node, nodes in item order) and emits the next level's items.
+__global__ __launch_bounds__(256) void gb_wide_link(const int* __restrict__ it_dst, const int* __restrict__ node_need, int cnt, const int* __restrict__ off, int base,
+                                                    DNode4* __restrict__ n4, int* __restrict__ nx_src, int* __restrict__ nx_dst, int* __restrict__ nx_need)
+{
+    int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= cnt) return;
+    DNode4& d = n4[it_dst[q]];
+    int j = off[q];
+    for (int k = 0; k < 4; k++) {
+        const int r = d.ref[k];
+        if (r < 0) continue;
+        nx_src[j] = r; nx_dst[j] = base + j; nx_need[j] = node_need[q];
+        d.ref[k] = base + j;
+        j++;
+    }
+}
+
 } // namespace
 
 // tris_dev: n triangles on the device. nodes_dev: 2n-1 nodes, tri_idx_dev: n indices, both written here.
@@ -181,7 +405,7 @@ int gpu_build_lbvh(const pt_triangle* tris_dev, int n, pt_bvh_node* nodes_dev, i
         GB_TRY(hipMalloc(&d_temp, temp_bytes));
         GB_TRY(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys, d_keys_sorted, d_ids, d_ids_sorted, n, 0, 63, stream));
         int* left = d_links; int* right = d_links + n; int* pin = d_links + 2 * (size_t)n; int* pleaf = d_links + 3 * (size_t)n;
-        if (n > 1) hipLaunchKernelGGL(gb_radix_tree, grid, block, 0, stream, d_keys_sorted, n, left, right, pin, pleaf);
+        if (n > 1) hipLaunchKernelGGL(gb_radix_tree, grid, block, 0, stream, d_keys_sorted, n, left, right, pin, pleaf, (int*)nullptr, (int*)nullptr);
         hipLaunchKernelGGL(gb_refit, grid, block, 0, stream, tris_dev, d_ids_sorted, n, left, right, pin, pleaf, d_visits, nodes_dev, tri_idx_dev);
         GB_TRY(hipGetLastError());
         GB_TRY(hipStreamSynchronize(stream));
@@ -196,6 +420,185 @@ done:
     if (d_keys) (void)hipFree(d_keys);
     if (d_bounds) (void)hipFree(d_bounds);
     return rc;
+}
+
+// tris_dev: n >= 2 triangles on the device. Builds the tree and every traversal layout on the device; tri_idx_host
+// receives the triangle order of the leaves (n entries).
+int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, GpuScene* out, int* tri_idx_host, hipStream_t stream)
+{
+    if (!tris_dev || n < 2 || !out || !tri_idx_host) { set_error("gpu_build_scene: bad argument"); return PT_ERR_ARG; }
+    int rc = PT_OK;
+    const int ni = n - 1;          // interior nodes
+    Bounds* d_bounds = nullptr;
+    uint64_t *d_keys = nullptr, *d_keys_sorted = nullptr;
+    uint32_t *d_ids = nullptr, *d_ids_sorted = nullptr, *d_misc = nullptr;
+    int *d_links = nullptr, *d_order = nullptr, *d_newid = nullptr, *d_kids = nullptr, *d_off = nullptr, *d_items = nullptr, *d_tri_idx = nullptr, *d_need = nullptr;
+    TightBox *d_tl = nullptr, *d_tr = nullptr;
+    NodeAux* d_aux = nullptr;
+    DNode4* d_n4_big = nullptr;
+    void *d_temp = nullptr, *d_scan_temp = nullptr;
+    size_t temp_bytes = 0, scan_bytes = 0;
+    GpuScene g;
+    const dim3 grid((n + 255) / 256), block(256);
+    auto blocks = [](int cnt) { return dim3((unsigned)((cnt + 255) / 256)); };
+    std::vector<int> level_start;
+    {
+        GB_TRY(hipMalloc((void**)&d_bounds, sizeof(Bounds)));
+        GB_TRY(hipMalloc((void**)&d_keys, (size_t)n * sizeof(uint64_t)));
+        GB_TRY(hipMalloc((void**)&d_keys_sorted, (size_t)n * sizeof(uint64_t)));
+        GB_TRY(hipMalloc((void**)&d_ids, (size_t)n * sizeof(uint32_t)));
+        GB_TRY(hipMalloc((void**)&d_ids_sorted, (size_t)n * sizeof(uint32_t)));
+        GB_TRY(hipMalloc((void**)&d_links, (size_t)n * 2 * sizeof(int)));
+        GB_TRY(hipMalloc((void**)&d_misc, 4 * sizeof(uint32_t)));         // [0] largest coordinate (float bits), [1] largest stack need, [2] bad box
+        Bounds init;
+        for (int a = 0; a < 3; a++) { init.lo[a] = 0xffffffffu; init.hi[a] = 0u; }
+        GB_TRY(hipMemcpyAsync(d_bounds, &init, sizeof(init), hipMemcpyHostToDevice, stream));
+        GB_TRY(hipMemsetAsync(d_misc, 0, 4 * sizeof(uint32_t), stream));
+        hipLaunchKernelGGL(gb_scene_bounds, grid, block, 0, stream, tris_dev, n, d_bounds);
+        hipLaunchKernelGGL(gb_morton, grid, block, 0, stream, tris_dev, n, d_bounds, d_keys, d_ids);
+        GB_TRY(hipGetLastError());
+        GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, temp_bytes, d_keys, d_keys_sorted, d_ids, d_ids_sorted, n, 0, 63, stream));
+        GB_TRY(hipMalloc(&d_temp, temp_bytes));
+        GB_TRY(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys, d_keys_sorted, d_ids, d_ids_sorted, n, 0, 63, stream));
+        int* left = d_links; int* right = d_links + n;
+        hipLaunchKernelGGL(gb_radix_tree, grid, block, 0, stream, d_keys_sorted, n, left, right, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr);
+        GB_TRY(hipGetLastError());
+        // the sort's buffers are free again: reuse is not worth the bookkeeping, release them before the big arrays come
+        GB_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(d_temp); d_temp = nullptr;
+        (void)hipFree(d_keys); d_keys = nullptr;
+        (void)hipFree(d_keys_sorted); d_keys_sorted = nullptr;
+        (void)hipFree(d_ids); d_ids = nullptr;
+
+        // ---- breadth-first numbering
+        GB_TRY(hipMalloc((void**)&d_order, (size_t)ni * sizeof(int)));
+        GB_TRY(hipMalloc((void**)&d_newid, (size_t)ni * sizeof(int)));
+        GB_TRY(hipMalloc((void**)&d_kids, (size_t)ni * sizeof(int)));
+        GB_TRY(hipMalloc((void**)&d_off, (size_t)ni * sizeof(int)));
+        GB_TRY(hipMalloc((void**)&d_need, (size_t)ni * sizeof(int)));
+        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_kids, d_off, ni, stream));
+        GB_TRY(hipMalloc(&d_scan_temp, scan_bytes));
+        GB_TRY(hipMemsetAsync(d_order, 0, sizeof(int), stream));          // the root of the radix tree is its node 0
+        GB_TRY(hipMemsetAsync(d_newid, 0, sizeof(int), stream));
+        level_start.push_back(0);
+        for (int lo = 0, cnt = 1; cnt > 0;) {
+            if ((int)level_start.size() > 4096) { set_error("gpu_build_scene: tree deeper than 4096 levels"); rc = PT_ERR_ARG; goto done; }
+            hipLaunchKernelGGL(gb_bfs_count, blocks(cnt), block, 0, stream, d_order, lo, cnt, left, right, d_kids);
+            GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_temp, scan_bytes, d_kids, d_off, cnt, stream));
+            hipLaunchKernelGGL(gb_bfs_emit, blocks(cnt), block, 0, stream, d_order, lo, cnt, left, right, d_off, d_newid);
+            GB_TRY(hipGetLastError());
+            int last[2];
+            GB_TRY(hipMemcpyAsync(&last[0], d_off + (cnt - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+            GB_TRY(hipMemcpyAsync(&last[1], d_kids + (cnt - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+            GB_TRY(hipStreamSynchronize(stream));
+            lo += cnt; cnt = last[0] + last[1];
+            level_start.push_back(lo);
+            if (lo + cnt > ni) { set_error("gpu_build_scene: the radix tree is not a tree"); rc = PT_ERR_HIP; goto done; }
+        }
+        if (level_start.back() != ni) { set_error("gpu_build_scene: %d of %d nodes reached from the root", level_start.back(), ni); rc = PT_ERR_HIP; goto done; }
+
+        // ---- triangle records, bottom-up pass
+        GB_TRY(hipMalloc((void**)&g.tris, ((size_t)n + 1) * sizeof(DTri)));
+        GB_TRY(hipMemsetAsync(g.tris + n, 0, sizeof(DTri), stream));      // one record of padding: leaves are read two records at a time
+        GB_TRY(hipMalloc((void**)&d_tri_idx, (size_t)n * sizeof(int)));
+        hipLaunchKernelGGL(gb_emit_tris, grid, block, 0, stream, tris_dev, d_ids_sorted, n, g.tris, d_tri_idx, d_misc);
+        GB_TRY(hipMalloc((void**)&g.nodes, (size_t)ni * sizeof(DNode)));
+        GB_TRY(hipMalloc((void**)&d_tl, (size_t)ni * sizeof(TightBox)));
+        GB_TRY(hipMalloc((void**)&d_tr, (size_t)ni * sizeof(TightBox)));
+        GB_TRY(hipMalloc((void**)&d_aux, (size_t)ni * sizeof(NodeAux)));
+        for (int l = (int)level_start.size() - 2; l >= 0; l--) {
+            const int lo = level_start[(size_t)l], cnt = level_start[(size_t)l + 1] - lo;
+            hipLaunchKernelGGL(gb_fit_level, blocks(cnt), block, 0, stream, tris_dev, d_ids_sorted, d_order, d_newid, left, right, lo, cnt, g.nodes, d_tl, d_tr, d_aux);
+        }
+        GB_TRY(hipGetLastError());
+        TightBox root_lr[2]; NodeAux root_aux; uint32_t misc[4];
+        GB_TRY(hipMemcpyAsync(&root_lr[0], d_tl, sizeof(TightBox), hipMemcpyDeviceToHost, stream));
+        GB_TRY(hipMemcpyAsync(&root_lr[1], d_tr, sizeof(TightBox), hipMemcpyDeviceToHost, stream));
+        GB_TRY(hipMemcpyAsync(&root_aux, d_aux, sizeof(NodeAux), hipMemcpyDeviceToHost, stream));
+        GB_TRY(hipMemcpyAsync(misc, d_misc, sizeof(misc), hipMemcpyDeviceToHost, stream));
+        GB_TRY(hipMemcpyAsync(tri_idx_host, d_tri_idx, (size_t)n * sizeof(int), hipMemcpyDeviceToHost, stream));
+        GB_TRY(hipStreamSynchronize(stream));
+        g.n_nodes = (size_t)ni;
+        g.stack_need_binary = root_aux.height;          // one pending sibling per level of the binary walk
+        QuantGrid qg;
+        for (int a = 0; a < 3; a++) {
+            g.root_min[a] = fminf(root_lr[0].lo[a], root_lr[1].lo[a]) - kPad;
+            g.root_max[a] = fmaxf(root_lr[0].hi[a], root_lr[1].hi[a]) + kPad;
+            double ext = (double)g.root_max[a] - g.root_min[a];
+            if (!(ext > 0.0)) ext = 1.0;
+            const double cell = ext / 65531.0;            // cells 2..65533 span the box, two cells of slack on each side
+            g.q_origin[a] = (float)((double)g.root_min[a] - 2.0 * cell);
+            g.q_cell[a] = (float)cell;
+            g.q_inv_cell[a] = (float)(1.0 / cell);
+            qg.origin[a] = g.q_origin[a]; qg.cell[a] = g.q_cell[a];
+        }
+        GB_TRY(hipMalloc((void**)&g.qnodes, (size_t)ni * sizeof(DNodeQ)));
+        hipLaunchKernelGGL(gb_quantize, blocks(ni), block, 0, stream, g.nodes, ni, qg, g.qnodes);
+        GB_TRY(hipGetLastError());
+
+        // ---- 4-wide nodes (the root is interior: n >= 2 and a subtree becomes a leaf only below it... unless the whole tree may)
+        float max_coord = 0.f;
+        memcpy(&max_coord, &misc[0], sizeof(float));
+        const double margin = ldexp(max_coord > 0.f ? (double)max_coord : 1.0, -19);
+        if (root_aux.mergeable && root_aux.count <= leaf_merge && root_aux.count <= 16) { set_error("gpu_build_scene: the whole scene is one leaf"); rc = PT_ERR_ARG; goto done; }
+        GB_TRY(hipMalloc((void**)&d_n4_big, (size_t)ni * sizeof(DNode4)));
+        GB_TRY(hipMalloc((void**)&d_items, (size_t)ni * 6 * sizeof(int)));
+        int* it[2][3] = {{d_items, d_items + ni, d_items + 2 * (size_t)ni}, {d_items + 3 * (size_t)ni, d_items + 4 * (size_t)ni, d_items + 5 * (size_t)ni}};
+        GB_TRY(hipMemsetAsync(d_items, 0, (size_t)ni * 6 * sizeof(int), stream));        // first item: binary node 0 -> wide node 0, need 0
+        int made = 1, cur = 0;
+        for (int cnt = 1, level = 0; cnt > 0; level++) {
+            if (level > 4096) { set_error("gpu_build_scene: wide tree deeper than 4096 levels"); rc = PT_ERR_ARG; goto done; }
+            hipLaunchKernelGGL(gb_wide_make, blocks(cnt), block, 0, stream, it[cur][0], it[cur][1], it[cur][2], cnt, g.nodes, d_tl, d_tr, d_aux, leaf_merge, margin,
+                               d_n4_big, d_kids, d_need, reinterpret_cast<int*>(d_misc) + 1);
+            GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_temp, scan_bytes, d_kids, d_off, cnt, stream));
+            hipLaunchKernelGGL(gb_wide_link, blocks(cnt), block, 0, stream, it[cur][1], d_need, cnt, d_off, made, d_n4_big, it[cur ^ 1][0], it[cur ^ 1][1], it[cur ^ 1][2]);
+            GB_TRY(hipGetLastError());
+            int last[2];
+            GB_TRY(hipMemcpyAsync(&last[0], d_off + (cnt - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+            GB_TRY(hipMemcpyAsync(&last[1], d_kids + (cnt - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+            GB_TRY(hipStreamSynchronize(stream));
+            cnt = last[0] + last[1];
+            if ((long long)made + cnt > ni) { set_error("gpu_build_scene: more wide nodes than binary nodes"); rc = PT_ERR_HIP; goto done; }
+            made += cnt; cur ^= 1;
+        }
+        GB_TRY(hipMemcpyAsync(misc, d_misc, sizeof(misc), hipMemcpyDeviceToHost, stream));
+        GB_TRY(hipMalloc((void**)&g.nodes4, (size_t)made * sizeof(DNode4)));
+        GB_TRY(hipMemcpyAsync(g.nodes4, d_n4_big, (size_t)made * sizeof(DNode4), hipMemcpyDeviceToDevice, stream));
+        GB_TRY(hipStreamSynchronize(stream));
+        g.n_nodes4 = (size_t)made;
+        g.stack_need_wide = (int)misc[1];
+        g.bad_box = misc[2] != 0;
+    }
+done:
+    if (d_items) (void)hipFree(d_items);
+    if (d_n4_big) (void)hipFree(d_n4_big);
+    if (d_aux) (void)hipFree(d_aux);
+    if (d_tr) (void)hipFree(d_tr);
+    if (d_tl) (void)hipFree(d_tl);
+    if (d_tri_idx) (void)hipFree(d_tri_idx);
+    if (d_scan_temp) (void)hipFree(d_scan_temp);
+    if (d_need) (void)hipFree(d_need);
+    if (d_off) (void)hipFree(d_off);
+    if (d_kids) (void)hipFree(d_kids);
+    if (d_newid) (void)hipFree(d_newid);
+    if (d_order) (void)hipFree(d_order);
+    if (d_temp) (void)hipFree(d_temp);
+    if (d_misc) (void)hipFree(d_misc);
+    if (d_links) (void)hipFree(d_links);
+    if (d_ids_sorted) (void)hipFree(d_ids_sorted);
+    if (d_ids) (void)hipFree(d_ids);
+    if (d_keys_sorted) (void)hipFree(d_keys_sorted);
+    if (d_keys) (void)hipFree(d_keys);
+    if (d_bounds) (void)hipFree(d_bounds);
+    if (rc != PT_OK) {
+        if (g.nodes) (void)hipFree(g.nodes);
+        if (g.qnodes) (void)hipFree(g.qnodes);
+        if (g.nodes4) (void)hipFree(g.nodes4);
+        if (g.tris) (void)hipFree(g.tris);
+        return rc;
+    }
+    *out = g;
+    return PT_OK;
 }
 
 } // namespace ptamd

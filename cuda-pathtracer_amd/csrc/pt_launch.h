@@ -21,6 +21,15 @@ hipError_t wf_static_scratch(int device, void** ptr_out);      // `device` must 
 hipError_t launch_wf_trace_static(void* base, const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, int refill_lanes, int leaf_vote,
                                   int extend_blocks, hipStream_t s);
 int gpu_build_lbvh(const pt_triangle* tris_dev, int n, pt_bvh_node* nodes_dev, int* tri_idx_dev, hipStream_t stream);
+// The traversal layouts of a tree built on the device. On success the caller owns the four arrays (hipFree).
+struct GpuScene {
+    DNode* nodes = nullptr; DNodeQ* qnodes = nullptr; DNode4* nodes4 = nullptr; DTri* tris = nullptr;
+    size_t n_nodes = 0, n_nodes4 = 0;
+    float root_min[3], root_max[3], q_origin[3], q_cell[3], q_inv_cell[3];
+    int stack_need_binary = 0, stack_need_wide = 0;
+    bool bad_box = false;
+};
+int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, GpuScene* out, int* tri_idx_host, hipStream_t stream);
 void launch_env_tables(const float* cdf_dev, int w, int h, float* row_table_dev, float* col_table_dev, hipStream_t stream);
 void launch_env_texel_guide(const DScene& S, uint2* guide_dev, uint32_t* mismatches_dev, hipStream_t stream);
 void launch_env_guides(const DScene& S, uint32_t* row_guide_dev, uint32_t* col_guide_dev, uint32_t* mismatches_dev, hipStream_t stream);

@@ -42,6 +42,7 @@ extern "C" {
 /* BVH build flavours for pt_host_build_bvh / pt_build_bvh */
 #define PT_BVH_REFERENCE 0   /* identical tree to BVH_builder.cpp:12-128, built with binned sweeps */
 #define PT_BVH_GPU_LBVH  1   /* pt_build_bvh only: Morton-order radix tree built on the GPU in milliseconds; same images (closest hits do not depend on the tree), different test counters */
+#define PT_BVH_GPU_LBVH_VIA_HOST 2   /* pt_build_bvh only: the same tree, copied to the host in the reference's node layout and taken in through pt_upload_bvh (cross-check of the device-side layouts) */
 
 typedef struct pt_float2 { float x, y; } pt_float2;
 typedef struct pt_float3 { float x, y, z; } pt_float3;
@@ -231,7 +232,7 @@ int pt_reset_counters(pt_ctx* ctx);
 int pt_enable_counters(pt_ctx* ctx, int on);                            /* instrumented kernels (slower); off by default. 1: the reference-order binary walk is traced and its box and triangle tests counted (equal to the reference's counts, pathtracer.cu:207,230); 2: the production walk over the wide nodes is traced and its own node visits and triangle tests counted (wide_nodes, wide_tris) */
 int pt_stage_timing(pt_ctx* ctx, int on, double* extend_ms_out, uint64_t* extend_launches_out); /* HIP-event time of the extend kernel: returns the totals since the last call, then switches timing on/off and clears them */
 int pt_debug_words(pt_ctx* ctx, unsigned long long* out16);                 /* diagnostic builds only: 16 statistics words of the traversal kernel, zeroed on read (all zero in a regular build) */
-int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* tri_bytes); /* size of the flattened BVH in HBM */
+int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* tri_bytes); /* bytes of the nodes the production traversal walks (4-wide, or quantized binary) and of the leaf-ordered triangle records */
 int pt_detmath_probe(pt_ctx* ctx, const float* x, const float* y, int n, float* out12); /* device evaluation of include/pt_detmath.h, 12 results per input pair */
 int pt_bsdf_probe(pt_ctx* ctx, const pt_material* mats, const int* inside, const float* V3, const float* N3, const float* L3, const uint32_t* pixel, int frame, int n, float* out12); /* device evaluation of the BSDF alone, item i on material record i: DisneyEval_2 (disney.cuh:234-347) for (V, N, L) -> f.xyz, pdf; DisneySample_2 (disney.cuh:348-460) for (V, N) with the random stream of (pixel[i], frame) -> L.xyz, f.xyz, pdf, inside flag afterwards */
 int pt_unorm8_probe(pt_ctx* ctx, float* out256);                         /* device evaluation of the byte -> float conversion of packed textures */

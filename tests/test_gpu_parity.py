@@ -629,6 +629,44 @@ def test_gpu_built_tree_gives_the_same_image():
         r.close()
 
 
+def test_device_side_layouts_equal_the_host_flattening_of_the_same_tree():
+    """pt_build_bvh(PT_BVH_GPU_LBVH) leaves binary, quantized and 4-wide nodes and the triangle records on the device
+    without a round trip; PT_BVH_GPU_LBVH_VIA_HOST takes the same radix tree through pt_upload_bvh's host code.
+    Same tree, same boxes: hits, and the test counts of the reference-order walk and of the production walk, agree
+    exactly (the node numbering differs, which no count sees)."""
+    Ps = ptamd.default_params(64, 48); Ps.rayOrigin = ptamd.Float3(0.0, 0.0, 700.0); Ps.isRendering = 1
+    cases = [(util.atrium(detail=0.35, env_size=(64, 32)), 1400.0, scenes.atrium_params(ptamd.default_params(64, 48))),
+             (util.soup(300000, seed=9, extent=400.0, edge=6.0), 450.0, Ps)]
+    for b, extent, P in cases:
+        rays = scenes.random_rays(200000, seed=5, extent=extent)
+        seen = []
+        for flavour in (lib.PT_BVH_GPU_LBVH, lib.PT_BVH_GPU_LBVH_VIA_HOST):
+            r = b.renderer(P)       # textures and environment, then the scene again with the tree under test
+            r.upload_scene(b.tris, b.mats, None, None, flavour=flavour)
+            slow = r.trace_closest(rays)
+            fast = r.trace_closest_fast(rays)
+            assert np.array_equal(slow['tri'], fast['tri']) and np.array_equal(bits(slow['t']), bits(fast['t']))
+            counts = []
+            for mode in (1, 2):
+                r.enable_counters(mode); r.reset_counters(); r.clear_accum()
+                r.render(P, 0, 2)
+                c = r.counters()
+                counts.append((c['rays'], c['box_tests'], c['tri_tests'], c['wide_nodes'], c['wide_tris']))
+            r.enable_counters(0)
+            image = r.read_accum()
+            for nw in (2, 4):       # the quantized binary nodes, then the wide ones again
+                r.set_node_width(nw)
+                again = r.trace_closest_fast(rays)
+                assert np.array_equal(again['tri'], slow['tri']) and np.array_equal(bits(again['t']), bits(slow['t']))
+            seen.append((slow, counts, r.scene_bytes(), image))
+            r.close()
+        (h0, c0, b0, i0), (h1, c1, b1, i1) = seen
+        assert np.array_equal(h0['tri'], h1['tri']) and np.array_equal(bits(h0['t']), bits(h1['t']))
+        assert np.array_equal(bits(i0), bits(i1))
+        assert c0 == c1, (c0, c1)
+        assert c0[0][1] > 0 and c0[1][3] > 0 and b0 == b1, (c0, b0, b1)
+
+
 def test_group_of_one_gpu_and_group_errors():
     """pt_group_render on one GPU is pt_render_headless; two contexts on one GPU are refused (a group takes one
     context per GPU; the RCCL reduce between GPUs cannot be exercised on a one-GPU machine)."""
