@@ -673,15 +673,16 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
 int pt_build_bvh(pt_ctx* c, int flavour)
 {
     if (!c || !c->have_tris) { set_error("pt_build_bvh: upload triangles first"); return PT_ERR_STATE; }
-    if (flavour != PT_BVH_REFERENCE && flavour != PT_BVH_GPU_LBVH && flavour != PT_BVH_GPU_LBVH_VIA_HOST) { set_error("pt_build_bvh: unknown flavour %d", flavour); return PT_ERR_ARG; }
+    if (flavour != PT_BVH_REFERENCE && flavour != PT_BVH_GPU_LBVH && flavour != PT_BVH_GPU_LBVH_VIA_HOST && flavour != PT_BVH_GPU_PLOC) { set_error("pt_build_bvh: unknown flavour %d", flavour); return PT_ERR_ARG; }
     int n = (int)c->tris.size();
-    if (flavour == PT_BVH_GPU_LBVH && n >= 64 && (size_t)n < ((size_t)1 << 26)) {
+    if (flavour == PT_BVH_GPU_PLOC && (n < 64 || (size_t)n >= ((size_t)1 << 26))) flavour = PT_BVH_GPU_LBVH;       // tiny and huge scenes: the radix tree through the host path
+    if ((flavour == PT_BVH_GPU_LBVH || flavour == PT_BVH_GPU_PLOC) && n >= 64 && (size_t)n < ((size_t)1 << 26)) {
         // tree and traversal layouts are made on the device; the host receives the leaf order and a few numbers
         c->epoch++;
         HIP_TRY(hipSetDevice(c->device));
         std::vector<int> new_idx((size_t)n);
         GpuScene g;
-        int rc = gpu_build_scene(c->d_tri_ref, n, c->leaf_merge, &g, new_idx.data(), c->stream);
+        int rc = gpu_build_scene(c->d_tri_ref, n, c->leaf_merge, flavour == PT_BVH_GPU_PLOC, &g, new_idx.data(), c->stream);
         if (rc != PT_OK) return rc;
         const int stack_capacity = 16 + 48      /* LDS entries + private spill entries of the traversal kernels */;
         if (g.stack_need_binary > stack_capacity) {

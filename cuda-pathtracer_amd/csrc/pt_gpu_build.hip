@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 #include "pt_internal.h"
 #include "pt_launch.h"
@@ -258,6 +259,108 @@ __global__ __launch_bounds__(256) void gb_emit_tris(const pt_triangle* __restric
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(max_coord_bits, __float_as_uint(m));      // non-negative floats order as integers
 }
 
+// ---------------------------------------------------------------- agglomerative tree (PLOC, Meister & Bittner 2018)
+// Clusters start as the triangles in Morton order. Every round each cluster looks at its kPlocRadius neighbours on
+// either side for the one with which it would form the smallest box; two clusters that choose each other merge.
+// The trees come out close to a full SAH sweep's in traversal cost, at a few more passes over the data than the
+// radix tree. Everything is decided by running sums, not by atomics: the same input gives the same tree.
+constexpr int kPlocRadius = 16;
+
+__global__ __launch_bounds__(256) void gb_ploc_init(const pt_triangle* __restrict__ tris, const uint32_t* __restrict__ ids, int n, int* __restrict__ cl_node, TightBox* __restrict__ cl_box)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    cl_node[i] = ~i;
+    cl_box[i] = tri_bounds(tris[ids[i]]);
+}
+
+__global__ __launch_bounds__(256) void gb_ploc_nearest(const TightBox* __restrict__ cl_box, int m, int radius, int* __restrict__ nn)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const TightBox me = cl_box[i];
+    double best = INFINITY; int pick = -1;
+    auto look = [&](int j) {
+        if (j < 0 || j >= m || j == i) return;
+        const TightBox u = join(me, cl_box[j]);
+        const double a = half_area(u.lo, u.hi);
+        if (a < best || pick < 0) { best = a; pick = j; }
+    };
+    // equal boxes: the partner of the pair (2k, 2k+1) is looked at first and wins ties, so that a run of identical
+    // clusters halves every round instead of merging one pair
+    look(i ^ 1);
+    for (int d = 1; d <= radius; d++) { if ((i - d) != (i ^ 1)) look(i - d); if ((i + d) != (i ^ 1)) look(i + d); }
+    nn[i] = pick;
+}
+
+// keep[i]: cluster i survives the round (alone, or as the merged pair); fresh[i]: it becomes a new node
+__global__ __launch_bounds__(256) void gb_ploc_flags(const int* __restrict__ nn, int m, int* __restrict__ keep, int* __restrict__ fresh)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m) return;
+    const int j = nn[i];
+    const bool pair = j >= 0 && nn[j] == i;
+    keep[i] = (!pair || i < j) ? 1 : 0;
+    fresh[i] = (pair && i < j) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void gb_ploc_apply(const int* __restrict__ nn, int m, const int* __restrict__ keep, const int* __restrict__ keep_off,
+                                                     const int* __restrict__ fresh, const int* __restrict__ fresh_off, int node_base,
+                                                     const int* __restrict__ cl_node, const TightBox* __restrict__ cl_box,
+                                                     int* __restrict__ nx_node, TightBox* __restrict__ nx_box, int* __restrict__ left, int* __restrict__ right)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m || !keep[i]) return;
+    const int at = keep_off[i];
+    if (fresh[i]) {
+        const int j = nn[i];
+        const int id = node_base + fresh_off[i];
+        left[id] = cl_node[i]; right[id] = cl_node[j];
+        nx_node[at] = id;
+        nx_box[at] = join(cl_box[i], cl_box[j]);
+    } else {
+        nx_node[at] = cl_node[i];
+        nx_box[at] = cl_box[i];
+    }
+}
+
+// leaves below every node of a level (bottom-up), then the first leaf position of every child (top-down): a subtree's
+// triangles become contiguous, left subtree first
+__global__ __launch_bounds__(256) void gb_count_level(const int* __restrict__ order, const int* __restrict__ newid, const int* __restrict__ left, const int* __restrict__ right,
+                                                      int lo, int cnt, int* __restrict__ count)
+{
+    int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= cnt) return;
+    const int r = order[lo + q];
+    const int L = left[r], R = right[r];
+    count[lo + q] = (L < 0 ? 1 : count[newid[L]]) + (R < 0 ? 1 : count[newid[R]]);
+}
+
+__global__ __launch_bounds__(256) void gb_first_level(const int* __restrict__ order, const int* __restrict__ newid, const int* __restrict__ left, const int* __restrict__ right,
+                                                      int lo, int cnt, const int* __restrict__ count, int* __restrict__ first, int* __restrict__ leaf_pos)
+{
+    int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= cnt) return;
+    const int r = order[lo + q];
+    const int L = left[r], R = right[r];
+    const int f = first[lo + q];
+    int nl;
+    if (L < 0) { leaf_pos[~L] = f; nl = 1; } else { const int c = newid[L]; first[c] = f; nl = count[c]; }
+    if (R < 0) leaf_pos[~R] = f + nl; else first[newid[R]] = f + nl;
+}
+
+__global__ __launch_bounds__(256) void gb_remap_leaves(int n, const int* __restrict__ leaf_pos, const uint32_t* __restrict__ ids_in, uint32_t* __restrict__ ids_out,
+                                                       int* __restrict__ left, int* __restrict__ right)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) ids_out[leaf_pos[i]] = ids_in[i];
+    if (i < n - 1) {
+        const int L = left[i], R = right[i];
+        if (L < 0) left[i] = ~leaf_pos[~L];
+        if (R < 0) right[i] = ~leaf_pos[~R];
+    }
+}
+
 struct QuantGrid { float origin[3], cell[3]; };
 
 // the binary nodes on the global 16-bit grid, two cells of padding (the fallback walk of the production kernel)
@@ -422,9 +525,10 @@ done:
     return rc;
 }
 
-// tris_dev: n >= 2 triangles on the device. Builds the tree and every traversal layout on the device; tri_idx_host
-// receives the triangle order of the leaves (n entries).
-int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, GpuScene* out, int* tri_idx_host, hipStream_t stream)
+// tris_dev: n >= 2 triangles on the device. Builds the tree (the radix tree over the Morton order, or the agglomerative
+// tree over the same order) and every traversal layout on the device; tri_idx_host receives the triangle order of the
+// leaves (n entries).
+int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, bool agglomerative, GpuScene* out, int* tri_idx_host, hipStream_t stream)
 {
     if (!tris_dev || n < 2 || !out || !tri_idx_host) { set_error("gpu_build_scene: bad argument"); return PT_ERR_ARG; }
     int rc = PT_OK;
@@ -433,8 +537,11 @@ int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, GpuScene
     uint64_t *d_keys = nullptr, *d_keys_sorted = nullptr;
     uint32_t *d_ids = nullptr, *d_ids_sorted = nullptr, *d_misc = nullptr;
     int *d_links = nullptr, *d_order = nullptr, *d_newid = nullptr, *d_kids = nullptr, *d_off = nullptr, *d_items = nullptr, *d_tri_idx = nullptr, *d_need = nullptr;
-    TightBox *d_tl = nullptr, *d_tr = nullptr;
+    TightBox *d_tl = nullptr, *d_tr = nullptr, *d_clbox = nullptr;
     NodeAux* d_aux = nullptr;
+    int *d_ploc = nullptr;          // cluster nodes (two generations), nearest neighbours, keep/fresh flags and their running sums
+    uint32_t* d_ids_dfs = nullptr;
+    int root = 0;
     DNode4* d_n4_big = nullptr;
     void *d_temp = nullptr, *d_scan_temp = nullptr;
     size_t temp_bytes = 0, scan_bytes = 0;
@@ -461,14 +568,51 @@ int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, GpuScene
         GB_TRY(hipMalloc(&d_temp, temp_bytes));
         GB_TRY(hipcub::DeviceRadixSort::SortPairs(d_temp, temp_bytes, d_keys, d_keys_sorted, d_ids, d_ids_sorted, n, 0, 63, stream));
         int* left = d_links; int* right = d_links + n;
-        hipLaunchKernelGGL(gb_radix_tree, grid, block, 0, stream, d_keys_sorted, n, left, right, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr);
-        GB_TRY(hipGetLastError());
-        // the sort's buffers are free again: reuse is not worth the bookkeeping, release them before the big arrays come
+        if (!agglomerative) {
+            hipLaunchKernelGGL(gb_radix_tree, grid, block, 0, stream, d_keys_sorted, n, left, right, (int*)nullptr, (int*)nullptr, (int*)nullptr, (int*)nullptr);
+            GB_TRY(hipGetLastError());
+        }
+        // the sort's buffers are free again: release them before the big arrays come
         GB_TRY(hipStreamSynchronize(stream));
         (void)hipFree(d_temp); d_temp = nullptr;
         (void)hipFree(d_keys); d_keys = nullptr;
         (void)hipFree(d_keys_sorted); d_keys_sorted = nullptr;
         (void)hipFree(d_ids); d_ids = nullptr;
+        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, (int*)nullptr, (int*)nullptr, n, stream));
+        GB_TRY(hipMalloc(&d_scan_temp, scan_bytes));
+        if (agglomerative) {
+            GB_TRY(hipMalloc((void**)&d_ploc, (size_t)n * 7 * sizeof(int)));
+            GB_TRY(hipMalloc((void**)&d_clbox, (size_t)n * 2 * sizeof(TightBox)));
+            int* cl_node[2] = {d_ploc, d_ploc + n};
+            int *nn = d_ploc + 2 * (size_t)n, *keep = d_ploc + 3 * (size_t)n, *keep_off = d_ploc + 4 * (size_t)n, *fresh = d_ploc + 5 * (size_t)n, *fresh_off = d_ploc + 6 * (size_t)n;
+            TightBox* cl_box[2] = {d_clbox, d_clbox + n};
+            hipLaunchKernelGGL(gb_ploc_init, grid, block, 0, stream, tris_dev, d_ids_sorted, n, cl_node[0], cl_box[0]);
+            int m = n, made = 0, cur = 0;
+            const int radius = getenv("PT_PLOC_RADIUS") ? atoi(getenv("PT_PLOC_RADIUS")) : kPlocRadius;
+            for (int round = 0; m > 1; round++) {
+                if (round > 4096) { set_error("gpu_build_scene: the agglomerative build did not converge"); rc = PT_ERR_HIP; goto done; }
+                hipLaunchKernelGGL(gb_ploc_nearest, blocks(m), block, 0, stream, cl_box[cur], m, radius, nn);
+                hipLaunchKernelGGL(gb_ploc_flags, blocks(m), block, 0, stream, nn, m, keep, fresh);
+                GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_temp, scan_bytes, keep, keep_off, m, stream));
+                GB_TRY(hipcub::DeviceScan::ExclusiveSum(d_scan_temp, scan_bytes, fresh, fresh_off, m, stream));
+                hipLaunchKernelGGL(gb_ploc_apply, blocks(m), block, 0, stream, nn, m, keep, keep_off, fresh, fresh_off, made, cl_node[cur], cl_box[cur],
+                                   cl_node[cur ^ 1], cl_box[cur ^ 1], left, right);
+                GB_TRY(hipGetLastError());
+                int last[4];
+                GB_TRY(hipMemcpyAsync(&last[0], keep_off + (m - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+                GB_TRY(hipMemcpyAsync(&last[1], keep + (m - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+                GB_TRY(hipMemcpyAsync(&last[2], fresh_off + (m - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+                GB_TRY(hipMemcpyAsync(&last[3], fresh + (m - 1), sizeof(int), hipMemcpyDeviceToHost, stream));
+                GB_TRY(hipStreamSynchronize(stream));
+                const int merged = last[2] + last[3];
+                if (merged <= 0 || last[0] + last[1] != m - merged) { set_error("gpu_build_scene: agglomerative round %d merged %d of %d clusters", round, merged, m); rc = PT_ERR_HIP; goto done; }
+                m -= merged; made += merged; cur ^= 1;
+            }
+            if (made != ni) { set_error("gpu_build_scene: %d of %d nodes made", made, ni); rc = PT_ERR_HIP; goto done; }
+            GB_TRY(hipMemcpy(&root, cl_node[cur], sizeof(int), hipMemcpyDeviceToHost));
+            if (root < 0 || root >= ni) { set_error("gpu_build_scene: bad root"); rc = PT_ERR_HIP; goto done; }
+            (void)hipFree(d_clbox); d_clbox = nullptr;
+        }
 
         // ---- breadth-first numbering
         GB_TRY(hipMalloc((void**)&d_order, (size_t)ni * sizeof(int)));
@@ -476,10 +620,8 @@ int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, GpuScene
         GB_TRY(hipMalloc((void**)&d_kids, (size_t)ni * sizeof(int)));
         GB_TRY(hipMalloc((void**)&d_off, (size_t)ni * sizeof(int)));
         GB_TRY(hipMalloc((void**)&d_need, (size_t)ni * sizeof(int)));
-        GB_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, d_kids, d_off, ni, stream));
-        GB_TRY(hipMalloc(&d_scan_temp, scan_bytes));
-        GB_TRY(hipMemsetAsync(d_order, 0, sizeof(int), stream));          // the root of the radix tree is its node 0
-        GB_TRY(hipMemsetAsync(d_newid, 0, sizeof(int), stream));
+        GB_TRY(hipMemcpyAsync(d_order, &root, sizeof(int), hipMemcpyHostToDevice, stream));      // (the root of the radix tree is its node 0)
+        GB_TRY(hipMemsetAsync(d_newid + root, 0, sizeof(int), stream));
         level_start.push_back(0);
         for (int lo = 0, cnt = 1; cnt > 0;) {
             if ((int)level_start.size() > 4096) { set_error("gpu_build_scene: tree deeper than 4096 levels"); rc = PT_ERR_ARG; goto done; }
@@ -497,6 +639,24 @@ int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, GpuScene
         }
         if (level_start.back() != ni) { set_error("gpu_build_scene: %d of %d nodes reached from the root", level_start.back(), ni); rc = PT_ERR_HIP; goto done; }
 
+        if (agglomerative) {
+            // leaf order: every subtree's triangles contiguous, left subtree first (the radix tree has that by construction)
+            int *count = d_kids, *first = d_off, *leaf_pos = d_ploc;
+            for (int l = (int)level_start.size() - 2; l >= 0; l--) {
+                const int lo = level_start[(size_t)l], cnt = level_start[(size_t)l + 1] - lo;
+                hipLaunchKernelGGL(gb_count_level, blocks(cnt), block, 0, stream, d_order, d_newid, left, right, lo, cnt, count);
+            }
+            GB_TRY(hipMemsetAsync(first, 0, sizeof(int), stream));
+            for (int l = 0; l + 1 < (int)level_start.size(); l++) {
+                const int lo = level_start[(size_t)l], cnt = level_start[(size_t)l + 1] - lo;
+                hipLaunchKernelGGL(gb_first_level, blocks(cnt), block, 0, stream, d_order, d_newid, left, right, lo, cnt, count, first, leaf_pos);
+            }
+            GB_TRY(hipMalloc((void**)&d_ids_dfs, (size_t)n * sizeof(uint32_t)));
+            hipLaunchKernelGGL(gb_remap_leaves, grid, block, 0, stream, n, leaf_pos, d_ids_sorted, d_ids_dfs, left, right);
+            GB_TRY(hipGetLastError());
+            GB_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(d_ids_sorted); d_ids_sorted = d_ids_dfs; d_ids_dfs = nullptr;
+        }
         // ---- triangle records, bottom-up pass
         GB_TRY(hipMalloc((void**)&g.tris, ((size_t)n + 1) * sizeof(DTri)));
         GB_TRY(hipMemsetAsync(g.tris + n, 0, sizeof(DTri), stream));      // one record of padding: leaves are read two records at a time
@@ -571,6 +731,9 @@ int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, GpuScene
     }
 done:
     if (d_items) (void)hipFree(d_items);
+    if (d_ploc) (void)hipFree(d_ploc);
+    if (d_clbox) (void)hipFree(d_clbox);
+    if (d_ids_dfs) (void)hipFree(d_ids_dfs);
     if (d_n4_big) (void)hipFree(d_n4_big);
     if (d_aux) (void)hipFree(d_aux);
     if (d_tr) (void)hipFree(d_tr);

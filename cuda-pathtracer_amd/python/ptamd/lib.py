@@ -16,6 +16,7 @@ PT_SKY_ENVMAP, PT_SKY_SUNSKY = 0, 1
 PT_BVH_REFERENCE = 0
 PT_BVH_GPU_LBVH = 1
 PT_BVH_GPU_LBVH_VIA_HOST = 2
+PT_BVH_GPU_PLOC = 3
 PT_MODE_WAVEFRONT, PT_MODE_SINGLE_KERNEL = 0, 1
 PT_NOALLOC_MAX_RAYS = 262144     # include/pt_capi.h
 

@@ -591,19 +591,25 @@ def test_repacked_pool_gives_the_same_image():
         r.close()
 
 
-def test_gpu_built_tree_gives_the_same_image():
-    """PT_BVH_GPU_LBVH: a Morton-order radix tree built on the device. Closest hits and therefore radiance do not
-    depend on the tree; only traversal cost and the box/triangle test counters do."""
+@pytest.mark.parametrize('flavour', [pytest.param(lib.PT_BVH_GPU_LBVH, id='radix_tree'), pytest.param(lib.PT_BVH_GPU_PLOC, id='agglomerative')])
+def test_gpu_built_tree_gives_the_same_image(flavour):
+    """PT_BVH_GPU_LBVH: a Morton-order radix tree built on the device; PT_BVH_GPU_PLOC: clusters in Morton order merged
+    with their nearest neighbours. Closest hits and therefore radiance do not depend on the tree; only traversal cost
+    and the box/triangle test counters do."""
     b = util.atrium(detail=0.35, env_size=(256, 128))
     P = scenes.atrium_params(ptamd.default_params(96, 56))
     want, st = orc.render(b.oracle(P), P, 0, 2, 32)
     rays = scenes.random_rays(100000, seed=21, extent=1400.0)
     brute = orc.closest_brute(b.oracle(), rays[:3000])
     r = b.renderer(P)
-    r.upload_scene(b.tris, b.mats, None, None, flavour=lib.PT_BVH_GPU_LBVH)
+    r.upload_scene(b.tris, b.mats, None, None, flavour=flavour)
     slow, fast = r.trace_closest(rays), r.trace_closest_fast(rays)
     assert np.array_equal(slow['tri'], fast['tri']) and np.array_equal(bits(slow['t']), bits(fast['t']))
     assert np.array_equal(slow['tri'][:3000], brute['tri']) and np.array_equal(bits(slow['t'][:3000]), bits(brute['t']))
+    r.set_node_width(2)
+    fast2 = r.trace_closest_fast(rays)
+    assert np.array_equal(slow['tri'], fast2['tri']) and np.array_equal(bits(slow['t']), bits(fast2['t']))
+    r.set_node_width(4)
     for mode in (0, 1):
         r.set_mode(mode)
         r.set_max_bounces(32)
@@ -614,15 +620,15 @@ def test_gpu_built_tree_gives_the_same_image():
         c = r.counters()
         assert c['rays'] == st['rays'] and c['shade_vertices'] == st['shade_vertices'] and c['tex_taps'] == st['tex_taps']
     r.close()
-    # degenerate inputs: one triangle, two, many coincident
-    for n in (1, 2, 64):
+    # degenerate inputs: one triangle, two, many coincident (64 and more are built and laid out on the device)
+    for n in (1, 2, 64, 300):
         s = util.soup(n, seed=40 + n, extent=20.0, edge=30.0)
         tris = s.tris.copy()
-        if n == 64:
+        if n >= 64:
             tris[:] = tris[0]
         rr = scenes.random_rays(5000, seed=2, extent=60.0)
         r = ptamd.Renderer(); r.init(ptamd.default_params(16, 16))
-        r.upload_scene(tris, s.mats, None, None, flavour=lib.PT_BVH_GPU_LBVH)
+        r.upload_scene(tris, s.mats, None, None, flavour=flavour)
         got = r.trace_closest_fast(rr)
         ref = orc.closest_brute(orc.Scene(tris, s.mats), rr)
         assert np.array_equal(got['tri'], ref['tri']) and np.array_equal(bits(got['t']), bits(ref['t'])), n

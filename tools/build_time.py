@@ -11,6 +11,7 @@ r = ptamd.Renderer(0); r.init(P)
 import ctypes as C
 from ptamd.lib import _p, check
 t = time.perf_counter(); check(lib.lib().pt_upload_triangles(r.h, None, _p(tris), C.c_int(n))); check(lib.lib().pt_upload_materials(r.h, _p(mats), C.c_int(len(mats)))); print('upload triangles %.2f s' % (time.perf_counter() - t), flush=True)
-for rep in range(2):
-    t = time.perf_counter(); check(lib.lib().pt_build_bvh(r.h, C.c_int(lib.PT_BVH_GPU_LBVH))); r.sync(); print('pt_build_bvh(GPU_LBVH) %.2f s' % (time.perf_counter() - t), flush=True)
+for name, flavour in (('GPU_LBVH', lib.PT_BVH_GPU_LBVH), ('GPU_PLOC', lib.PT_BVH_GPU_PLOC), ('GPU_LBVH_VIA_HOST', lib.PT_BVH_GPU_LBVH_VIA_HOST)):
+    for rep in range(2):
+        t = time.perf_counter(); check(lib.lib().pt_build_bvh(r.h, C.c_int(flavour))); r.sync(); print('pt_build_bvh(%s) %.3f s' % (name, time.perf_counter() - t), flush=True)
 r.close()
