@@ -67,6 +67,7 @@ def main():
     ap.add_argument('--drain', type=int, default=-1, help='finish the last paths in one kernel once at most this many remain (-1 = library default, 0 = never)')
     ap.add_argument('--node-width', type=int, default=4, help='4-wide or binary (2) compact nodes in the traversal kernel')
     ap.add_argument('--leaf-merge', type=int, default=2, help='triangles per wide leaf at most')
+    ap.add_argument('--tree', choices=['host', 'lbvh', 'ploc'], default='', help='tree builder: host (the reference builder; atrium default), lbvh (radix tree on the GPU; soup default), ploc (agglomerative on the GPU)')
     ap.add_argument('--tune', type=str, default='', help='refill_lanes,leaf_vote,blocks_per_cu for the traversal kernel')
     args = ap.parse_args()
 
@@ -111,10 +112,11 @@ def main():
         P.isRendering = 1
         r = ptamd.Renderer(device)
         r.init(P)
-        r.upload_scene(tris, mats, None, None, flavour=ptlib.PT_BVH_GPU_LBVH)
+        soup_flavour = ptlib.PT_BVH_GPU_PLOC if args.tree == 'ploc' else ptlib.PT_BVH_GPU_LBVH
+        r.upload_scene(tris, mats, None, None, flavour=soup_flavour)
         r.upload_envmap(env4, cdf, env_total, P)
         n_tris = len(tris)
-        workload_name = 'soup of %d random triangles (tree built on the GPU), 256x128 HDR envmap' % n_tris
+        workload_name = 'soup of %d random triangles (%s tree built on the GPU), 256x128 HDR envmap' % (n_tris, 'agglomerative' if args.tree == 'ploc' else 'radix')
     else:
         if args.workload == 'sunsky':
             bundle = util.atrium(detail=detail, glossy=0.3, glass=0.2, sky_mode=1)
@@ -136,7 +138,11 @@ def main():
         if bundle is not None:
             r.upload_scene(bundle.tris, bundle.mats, bundle.idx, bundle.nodes)
         else:
-            r.upload_scene(tris, mats, None, None, flavour=ptlib.PT_BVH_GPU_LBVH)
+            r.upload_scene(tris, mats, None, None, flavour=soup_flavour)
+    if bundle is not None and args.tree in ('lbvh', 'ploc'):
+        from ptamd import lib as ptlib
+        r.upload_scene(bundle.tris, bundle.mats, None, None, flavour=ptlib.PT_BVH_GPU_PLOC if args.tree == 'ploc' else ptlib.PT_BVH_GPU_LBVH)
+        workload_name += ', %s tree built on the GPU' % ('agglomerative' if args.tree == 'ploc' else 'radix')
     if args.drain >= 0:
         r.set_drain(args.drain)
     if args.lanes:
