@@ -33,6 +33,22 @@ __global__ void stream_kernel(float* out, int iters, float a, float b)
                 asm volatile("v_max3_f32 %0, %0, %8, %9\n v_min3_f32 %1, %1, %8, %9\n v_max3_f32 %2, %2, %8, %9\n v_min3_f32 %3, %3, %8, %9\n"
                              "v_max3_f32 %4, %4, %8, %9\n v_min3_f32 %5, %5, %8, %9\n v_max3_f32 %6, %6, %8, %9\n v_min3_f32 %7, %7, %8, %9\n"
                              : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+            } else if (KIND == 6) {      // mixed-precision fma: half-precision first operand, converted inside the instruction
+                asm volatile("v_fma_mix_f32 %0, %8, %9, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %8, %9, %1 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %8, %9, %2 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %3, %8, %9, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             "v_fma_mix_f32 %4, %8, %9, %4 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %5, %8, %9, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n v_fma_mix_f32 %6, %8, %9, %6 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %7, %8, %9, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(u0), "v"(b));
+            } else if (KIND == 7) {      // integer and bit-field work
+                asm volatile("v_bfe_u32 %0, %8, 8, 8\n v_and_b32 %1, %8, %9\n v_lshlrev_b32 %2, 16, %8\n v_perm_b32 %3, %8, %9, %8\n"
+                             "v_bfe_u32 %4, %9, 16, 8\n v_and_b32 %5, %9, %8\n v_lshlrev_b32 %6, 8, %9\n v_perm_b32 %7, %9, %8, %9\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(u0), "v"(u1));
+            } else if (KIND == 8) {      // two-operand min/max and mul/add
+                asm volatile("v_min_f32 %0, %0, %8\n v_max_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %9\n"
+                             "v_min_f32 %4, %4, %8\n v_max_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %9\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b));
+            } else if (KIND == 9) {      // selects alone (the condition stays in vcc)
+                asm volatile("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc\n"
+                             "v_cndmask_b32 %4, %4, %9, vcc\n v_cndmask_b32 %5, %5, %9, vcc\n v_cndmask_b32 %6, %6, %9, vcc\n v_cndmask_b32 %7, %7, %9, vcc\n"
+                             : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a), "v"(b) : "vcc");
             } else if (KIND == 4) {      // a dependent chain: each instruction needs the one before it
                 asm volatile("v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
                              "v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n v_fma_f32 %0, %0, %1, %2\n"
@@ -80,6 +96,10 @@ int main()
     run<3>("v_max3/min3_f32", out, p.multiProcessorCount, ghz);
     run<4>("v_fma_f32 dependent chain", out, p.multiProcessorCount, ghz);
     run<5>("v_cmp + v_cndmask pairs", out, p.multiProcessorCount, ghz);
+    run<6>("v_fma_mix_f32 (f16 operand)", out, p.multiProcessorCount, ghz);
+    run<7>("bfe / and / lshl / perm", out, p.multiProcessorCount, ghz);
+    run<8>("min / max / mul / add f32", out, p.multiProcessorCount, ghz);
+    run<9>("v_cndmask_b32 alone", out, p.multiProcessorCount, ghz);
     CHECK(hipFree(out));
     return 0;
 }
