@@ -73,6 +73,17 @@ struct pt_ctx {
     float* accum = nullptr;         // 3*W*H, the buffer rendered into
     float* own_accum = nullptr;     // allocated by pt_init
     uint8_t* display = nullptr;     // 4*W*H
+    // pt_render_frame_async: two display buffers on the device, two pinned ones on the host, a stream for the copies
+    struct AsyncFrames {
+        uint8_t* dev[2] = {nullptr, nullptr};
+        uint8_t* host[2] = {nullptr, nullptr};
+        hipEvent_t resolved[2] = {nullptr, nullptr}, copied[2] = {nullptr, nullptr};
+        bool pending[2] = {false, false};       // copied or being copied, not fetched yet
+        int frame[2] = {0, 0};
+        int next = 0, oldest = 0;
+        hipStream_t copy_stream = nullptr;
+        size_t bytes = 0;
+    } af;
     // scene, host copies
     std::vector<pt_triangle> tris;
     std::vector<int> tri_idx;
@@ -191,6 +202,20 @@ int pt_create(pt_ctx** out, int device_id)
     return PT_OK;
 }
 
+static void free_async_frames(pt_ctx* c)
+{
+    pt_ctx::AsyncFrames& A = c->af;
+    if (A.copy_stream) (void)hipStreamSynchronize(A.copy_stream);
+    for (int b = 0; b < 2; b++) {
+        if (A.dev[b]) (void)hipFree(A.dev[b]);
+        if (A.host[b]) (void)hipHostFree(A.host[b]);
+        if (A.resolved[b]) (void)hipEventDestroy(A.resolved[b]);
+        if (A.copied[b]) (void)hipEventDestroy(A.copied[b]);
+    }
+    if (A.copy_stream) (void)hipStreamDestroy(A.copy_stream);
+    A = pt_ctx::AsyncFrames{};
+}
+
 static void free_scene_geometry(pt_ctx* c)
 {
     if (c->d_tris) { (void)hipFree(c->d_tris); c->d_tris = nullptr; }
@@ -217,6 +242,7 @@ void pt_destroy(pt_ctx* c)
     if (c->d_env_texel_guide) (void)hipFree(c->d_env_texel_guide);
     if (c->own_accum) (void)hipFree(c->own_accum);
     if (c->display) (void)hipFree(c->display);
+    free_async_frames(c);
     if (c->d_ctr) (void)hipFree(c->d_ctr);
     for (int i = 0; i < pt_ctx::kMaxLanes; i++) {
         pt_ctx::WfLane& L = c->lanes[i];
@@ -252,6 +278,7 @@ int pt_init(pt_ctx* c, const pt_params* p)
     HIP_TRY(hipSetDevice(c->device));
     if (c->own_accum) { (void)hipFree(c->own_accum); c->own_accum = nullptr; c->accum = nullptr; }
     if (c->display) { (void)hipFree(c->display); c->display = nullptr; }
+    free_async_frames(c);
     HIP_TRY(hipMalloc((void**)&c->own_accum, (size_t)W * H * 3 * sizeof(float)));
     c->accum = c->own_accum;
     HIP_TRY(hipMalloc((void**)&c->display, (size_t)W * H * 4));
@@ -1329,7 +1356,8 @@ int pt_set_frame_lookahead(pt_ctx* c, int max_frames)
     return PT_OK;
 }
 
-int pt_render_frame(pt_ctx* c, pt_params* P)
+// One frame of the reference's loop up to and including its addition to the accumulator (no resolve, no copy).
+static int render_frame_core(pt_ctx* c, pt_params* P)
 {
     int rc = check_ready(c, true);
     if (rc != PT_OK) return rc;
@@ -1371,10 +1399,71 @@ int pt_render_frame(pt_ctx* c, pt_params* P)
         if ((rc = pt_render_headless(c, P, P->frameIndex, P->frameIndex + 1)) != PT_OK) return rc;
     }
     A.params = *P; A.epoch = c->epoch; A.last_frame = P->isRendering ? P->frameIndex : -2;
+    return PT_OK;
+}
+
+int pt_render_frame(pt_ctx* c, pt_params* P)
+{
+    int rc = render_frame_core(c, P);
+    if (rc != PT_OK) return rc;
     launch_resolve_display(c->accum, c->W * c->H, P->isRendering ? P->frameIndex + 1 : 1, c->display, c->stream);
     HIP_TRY(hipGetLastError());
     if (P->pixelBuffer) HIP_TRY(hipMemcpyAsync(P->pixelBuffer, c->display, (size_t)c->W * c->H * 4, hipMemcpyDeviceToHost, c->stream));
     return pt_sync(c);
+}
+
+// pt_render_frame without the wait: the frame is rendered and added as above, its display image is resolved into one
+// of two device buffers and copied to one of two pinned host buffers on a stream of its own; the call returns when
+// the work is queued. While the caller keeps a frame in flight, the copy of frame f runs beside the rendering of
+// frame f + 1. pt_frame_fetch hands the frames out in order.
+int pt_render_frame_async(pt_ctx* c, pt_params* P)
+{
+    if (!c) { set_error("null context"); return PT_ERR_ARG; }
+    pt_ctx::AsyncFrames& F = c->af;
+    const size_t bytes = (size_t)c->W * c->H * 4;
+    if (F.pending[F.next]) { set_error("pt_render_frame_async: two frames are in flight, fetch one first"); return PT_ERR_STATE; }
+    int rc = render_frame_core(c, P);
+    if (rc != PT_OK) return rc;
+    if (!F.copy_stream || F.bytes != bytes) {
+        free_async_frames(c);
+        HIP_TRY(hipStreamCreateWithFlags(&F.copy_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(hipMalloc((void**)&F.dev[b], bytes));
+            HIP_TRY(hipHostMalloc((void**)&F.host[b], bytes, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&F.resolved[b], hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&F.copied[b], hipEventDisableTiming));
+        }
+        F.bytes = bytes;
+    }
+    const int b = F.next;
+    // (the buffer's last copy was fetched, hence finished, before this call could reuse it)
+    launch_resolve_display(c->accum, c->W * c->H, P->isRendering ? P->frameIndex + 1 : 1, F.dev[b], c->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(F.resolved[b], c->stream));
+    HIP_TRY(hipStreamWaitEvent(F.copy_stream, F.resolved[b], 0));
+    HIP_TRY(hipMemcpyAsync(F.host[b], F.dev[b], bytes, hipMemcpyDeviceToHost, F.copy_stream));
+    HIP_TRY(hipEventRecord(F.copied[b], F.copy_stream));
+    F.pending[b] = true; F.frame[b] = P->frameIndex;
+    F.next = b ^ 1;
+    return PT_OK;
+}
+
+// The oldest frame in flight: waits for its copy, then copies it into rgba_out (when given) and returns the pinned
+// buffer itself in *pinned_out (when given; valid until the second pt_render_frame_async call from now).
+int pt_frame_fetch(pt_ctx* c, uint8_t* rgba_out, const uint8_t** pinned_out, int* frame_index_out)
+{
+    if (!c) { set_error("null context"); return PT_ERR_ARG; }
+    pt_ctx::AsyncFrames& F = c->af;
+    const int b = F.oldest;
+    if (!F.pending[b]) { set_error("pt_frame_fetch: no frame in flight"); return PT_ERR_STATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipEventSynchronize(F.copied[b]));
+    if (rgba_out) memcpy(rgba_out, F.host[b], F.bytes);
+    if (pinned_out) *pinned_out = F.host[b];
+    if (frame_index_out) *frame_index_out = F.frame[b];
+    F.pending[b] = false;
+    F.oldest = b ^ 1;
+    return PT_OK;
 }
 
 int pt_read_accum(pt_ctx* c, float* out)

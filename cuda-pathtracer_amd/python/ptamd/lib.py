@@ -22,7 +22,7 @@ PT_NOALLOC_MAX_RAYS = 262144     # include/pt_capi.h
 
 EXPORTS = [
     'pt_last_error', 'pt_create', 'pt_destroy', 'pt_set_stream', 'pt_init', 'pt_clear_accum', 'pt_upload_triangles',
-    'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_set_frame_lookahead', 'pt_upload_texture', 'pt_upload_envmap',
+    'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_render_frame_async', 'pt_frame_fetch', 'pt_set_frame_lookahead', 'pt_upload_texture', 'pt_upload_envmap',
     'pt_set_sky_mode', 'pt_set_env_guides', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_set_repack', 'pt_wavefront_stats', 'pt_set_lanes', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_group_create', 'pt_group_frames', 'pt_group_render', 'pt_group_destroy', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
     'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_save_exr', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
     'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_trace_closest_noalloc_dev', 'pt_debug_words', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
@@ -297,6 +297,19 @@ class Renderer:
         check(lib().pt_render_frame(self.h, C.byref(params)))
         params.pixelBuffer = None
         return buf
+
+    def render_frame_async(self, params):
+        """Queues one frame; the image is fetched later with frame_fetch (at most two frames in flight)."""
+        params.pixelBuffer = None
+        check(lib().pt_render_frame_async(self.h, C.byref(params)))
+
+    def frame_fetch(self):
+        """(RGBA8 image, frame index) of the oldest frame in flight."""
+        W, H = self.params.windowSize.x, self.params.windowSize.y
+        buf = np.zeros((H, W, 4), dtype=np.uint8)
+        idx = C.c_int(-1)
+        check(lib().pt_frame_fetch(self.h, buf.ctypes.data_as(C.c_void_p), None, C.byref(idx)))
+        return buf, idx.value
 
     def sync(self):
         check(lib().pt_sync(self.h))

@@ -673,6 +673,44 @@ def test_device_side_layouts_equal_the_host_flattening_of_the_same_tree():
         assert c0[0][1] > 0 and c0[1][3] > 0 and b0 == b1, (c0, b0, b1)
 
 
+def test_async_frames_equal_the_blocking_frame_loop():
+    """pt_render_frame_async / pt_frame_fetch (display image to pinned host memory on a copy stream, two frames in
+    flight) hand out, in order, exactly the images of the blocking pt_render_frame loop, and leave the same accumulator."""
+    b = util.cornell('sky')
+    P = scenes.cornell_params(ptamd.default_params(96, 64))
+    r = b.renderer(P)
+    r.set_max_bounces(6)
+    n = 11
+    want = []
+    for f in range(n):
+        P.frameIndex = f
+        want.append(r.render_frame(P))
+    acc = r.read_accum()
+    got = []
+    for f in range(n):
+        P.frameIndex = f
+        r.render_frame_async(P)
+        if f >= 1:
+            img, idx = r.frame_fetch()
+            assert idx == f - 1
+            got.append(img)
+    img, idx = r.frame_fetch()
+    assert idx == n - 1
+    got.append(img)
+    for f in range(n):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(bits(r.read_accum()), bits(acc))
+    with pytest.raises(ptamd.PtError, match='no frame in flight'):
+        r.frame_fetch()
+    P.frameIndex = 0
+    r.render_frame_async(P); P.frameIndex = 1; r.render_frame_async(P); P.frameIndex = 2
+    with pytest.raises(ptamd.PtError, match='two frames are in flight'):
+        r.render_frame_async(P)
+    assert r.frame_fetch()[1] == 0 and r.frame_fetch()[1] == 1
+    assert np.array_equal(r.render_frame(P), want[2])
+    r.close()
+
+
 def test_group_of_one_gpu_and_group_errors():
     """pt_group_render on one GPU is pt_render_headless; two contexts on one GPU are refused (a group takes one
     context per GPU; the RCCL reduce between GPUs cannot be exercised on a one-GPU machine)."""

@@ -18,10 +18,18 @@ t0 = time.perf_counter()
 for f in range(n):
     P.frameIndex = f; r.render_frame(P)
 t1 = time.perf_counter()
+# the same loop with one frame kept in flight: the copy of frame f runs beside the work of frame f + 1
+ta = time.perf_counter()
+for f in range(n):
+    P.frameIndex = f; r.render_frame_async(P)
+    if f: r.frame_fetch()
+r.frame_fetch()
+tb = time.perf_counter()
 r.clear_accum(); r.render(P, 0, n)
 t2 = time.perf_counter()
 r.clear_accum(); r.render(P, 0, n)
 t3 = time.perf_counter()
 print('rays for %d frames: %d' % (n, rays))
 print('pt_render_frame x%d: %.1f ms/frame, %.1f Mrays/s (host RGBA8 copy + sync every frame)' % (n, (t1 - t0) / n * 1e3, rays / (t1 - t0) / 1e6))
+print('pt_render_frame_async + pt_frame_fetch x%d: %.1f ms/frame, %.1f Mrays/s (pinned double buffer, copy stream)' % (n, (tb - ta) / n * 1e3, rays / (tb - ta) / 1e6))
 print('pt_render_headless [0,%d): %.1f ms total, %.1f Mrays/s' % (n, (t3 - t2) * 1e3, rays / (t3 - t2) / 1e6))
