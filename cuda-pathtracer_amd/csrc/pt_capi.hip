@@ -140,6 +140,7 @@ struct pt_ctx {
         size_t pool_slots = 0;          // slots each of the block's two pools has room for
         int pool_side = 0;              // which of the two pools w points into
         bool all_started = false;       // the host has seen every sample id handed out to some workgroup
+        uint64_t issued = 0, issue_cap = 0;   // stage iterations issued for the current chunk, and the most it can need
     };
     static constexpr int kMaxLanes = 2;
     WfLane lanes[kMaxLanes];
@@ -1098,6 +1099,7 @@ static int lane_issue_batch(pt_ctx* c, pt_ctx::WfLane& L, const DCamera& cam, DC
         launch_wf_iteration(L.w, c->scene, cam, ctr, L.stream, c->stage_timing ? L.st_ev[2 * i] : nullptr, c->stage_timing ? L.st_ev[2 * i + 1] : nullptr);
     HIP_TRY(hipGetLastError());
     c->wf_iterations += L.batch;
+    L.issued += (uint64_t)L.batch;
     HIP_TRY(hipMemcpyAsync(L.host_counters, L.counters, WF_CTR_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, L.stream));
     HIP_TRY(hipEventRecord(L.ready, L.stream));
     return PT_OK;
@@ -1165,6 +1167,12 @@ static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1
             L.batch = (size_t)L.w.n_slots >= (size_t)L.w.n_samples ? 2 : kMaxBatch;
             L.finished = false;
             L.all_started = false;
+            // A sample visits at most (bounce cap + 1) vertices, each at most one path ray, one light sample of up to 32
+            // visibility segments (pathtracer.cu:279) and one bsdf stage; a slot runs its share of the samples one after
+            // the other. A loop that passes this bound is not going to end (a slot that keeps looking live): stop with
+            // an error instead of occupying the GPU for ever.
+            L.issued = 0;
+            L.issue_cap = ((uint64_t)L.w.n_samples / (uint64_t)L.w.n_slots + 2u) * ((uint64_t)c->max_bounces + 1u) * 34u + 64u;
             rc = lane_issue_batch(c, L, cam, ctr);
             if (rc != PT_OK) return rc;
         }
@@ -1195,6 +1203,10 @@ static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1
                     (uint64_t)hc[WF_CTR_RAYS] * 100u <= (uint64_t)L.w.n_slots * (uint64_t)c->repack_percent && L.w.n_slots > 256) {
                     int rc = lane_repack(c, L, hc[WF_CTR_RAYS]);
                     if (rc != PT_OK) return rc;
+                }
+                if (!done && L.issued > L.issue_cap) {
+                    set_error("render: lane %d still has live paths after %llu stage iterations (bound %llu)", i, (unsigned long long)L.issued, (unsigned long long)L.issue_cap);
+                    return PT_ERR_STATE;
                 }
                 if (done) {
                     if (!hold) launch_wf_accumulate(L.w, cam, c->accum, 0, L.w.n_frames, L.stream);
