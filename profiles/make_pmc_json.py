@@ -59,7 +59,7 @@ def main():
         'atrium': entry(d, '', [1920, 1080, 64, 512], tag,
                         'The scene (about 30 MB) is served from L2 / Infinity Cache, so memory-side traffic is far below the algorithmic byte count.'),
         'soup': entry(d, 'soup_', [1920, 1080, 16, 512], tag,
-                      'The 1.1 GB of nodes and triangles fit no cache: memory-side traffic is about the algorithmic byte count.'),
+                      'The 0.8 GB of wide nodes and triangle records fit no cache: memory-side traffic is about the algorithmic byte count.'),
     }
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'pmc_traffic.json'), 'w') as f:
         json.dump(out, f, indent=1)
