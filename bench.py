@@ -293,7 +293,7 @@ def main():
                          'note': ('achieved = bytes the timed kernel asks the memory system for (48 per ray in the slot arrays + 64 per wide node it visits + 48 per triangle it tests, '
                                   'counted on the production walk) / its mean launch time; reference_walk = the same with the layout-independent accounting on the reference\'s binary walk '
                                   '(40 + 32 per box test + 48 per triangle test). '
-                                  + ('The 30 MB scene is served from L2 / Infinity Cache, so this fraction measures cache gather rate against the HBM peak, not HBM use: traffic (PMC) is what reaches memory, '
+                                  + ('The %.0f MB the walk touches are served from L2 / Infinity Cache,' % ((node_b + tri_b) / 1e6) + ' so this fraction measures cache gather rate against the HBM peak, not HBM use: traffic (PMC) is what reaches memory, '
                                      'and the kernel is bound by vector instruction issue (issue).' if args.workload != 'soup' else
                                      'The %.1f GB of wide nodes and triangle records fit no cache: the node and triangle reads are random 64-byte HBM accesses; see traffic and issue.' % ((node_b + tri_b) / 1e9))),
                          'whole_path_algorithmic_GBs': round(algorithmic_bytes(loc) / (elapsed * 1e9), 2)},
