@@ -319,6 +319,9 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
 #ifndef PT_TAIL_FACTOR
 #define PT_TAIL_FACTOR 2u
 #endif
+#ifndef PT_STAMPS_SHADE
+#define PT_STAMPS_SHADE 0     // diagnostic build: section clocks of the shade kernel
+#endif
 #ifndef PT_STAMPS
 #define PT_STAMPS 0      // diagnostic build: pass statistics of the extend kernel
 #endif
@@ -619,6 +622,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE
 {
     uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     if (slot >= (uint32_t)w.n_slots) return;
+    // counters of the bsdf queue's counting sort (below): zeroed here, where a barrier costs nothing yet
+    constexpr int kKinds = 64;
+    __shared__ uint32_t s_kind[kKinds];
+    if (threadIdx.x < kKinds) s_kind[threadIdx.x] = 0u;
+    __syncthreads();
+#if PT_STAMPS_SHADE
+    // diagnostic build: where a wave's time goes (section clocks, memory waits drained at each stamp)
+    unsigned long long sst[8];
+    unsigned long long ssl[4] = {0, 0, 0, 0};
+#define SST(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); sst[i] = __builtin_amdgcn_s_memtime(); } while (0)
+    SST(0);
+#else
+#define SST(i) do { } while (0)
+#endif
     float4 rd4 = w.ray_d[slot];
     bool live = __float_as_int(rd4.w) != 0;
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
@@ -635,16 +652,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE
         Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
         F3 rdir = f3(rd4.x, rd4.y, rd4.z);
         Surf info;
+        SST(1);
         resolve_hit<COUNT>(S, h, rdir, info, tl.taps, tl.taps_r, P.state == ST_SHADOW);
+        SST(2);
+#if PT_STAMPS_SHADE
+        ssl[0] = (unsigned long long)__popcll(__ballot(true)); ssl[1] = (unsigned long long)__popcll(__ballot(P.state == ST_SHADOW));
+        ssl[2] = (unsigned long long)__popcll(__ballot(h.tri == PT_NO_TRI));
+        sst[3] = sst[2];
+#endif
         if (P.state == ST_SHADOW) {
             P.so = f3(ro4.x, ro4.y, ro4.z); P.sd = rdir;
             on_shadow_hit<COUNT>(S, cam, P, info, tl);
+            SST(3);
         } else {
             on_path_hit<COUNT>(S, cam, P, info, tl);
             if (P.state == ST_SHADOW || P.state == ST_AFTER) store_vertex(w, slot, P);
         }
         finished = P.state == ST_DONE;
     }
+#if PT_STAMPS_SHADE
+    else { sst[1] = sst[2] = sst[3] = sst[0]; }
+#endif
+    SST(4);
     // Slots that reached the bsdf stage go into the workgroup's segment of the queue (block b owns entries
     // [b*256, b*256 + count[b]); no global atomics), ordered by the kind of work the stage will do for them: which
     // lobes the material carries (the branches of DisneyEval_2, disney.cuh:294-344), surface or medium vertex, and
@@ -652,32 +681,45 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE
     // LDS: the waves of the bsdf stage then run mostly one kind each instead of every branch for a few lanes.
     bool to_bsdf = live && P.state == ST_AFTER;
     {
-        constexpr int kKinds = 64;
-        __shared__ uint32_t s_kind[kKinds];
-        if (threadIdx.x < kKinds) s_kind[threadIdx.x] = 0u;
-        __syncthreads();
+        // (s_kind was zeroed at the top of the kernel, a barrier ago)
+        const int lane = (int)(threadIdx.x & 63u);
         uint32_t kind = 0, rank = 0;
         if (to_bsdf) {
             const bool lit = !P.nee_skip && !(dot(P.light, P.light) <= 0.05f);
             kind = (uint32_t)(P.lobes & 15) | (P.nee_surface ? 0u : 16u) | (lit ? 32u : 0u);
-            rank = atomicAdd(&s_kind[kind], 1u);
+        }
+        // one LDS atomic per kind a wave holds (a wave's lanes are mostly of one or two kinds: per-lane atomics on
+        // one word would be served one after the other)
+        for (unsigned long long todo = __ballot(to_bsdf); todo != 0ull;) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t k = (uint32_t)__shfl((int)kind, leader, 64);
+            const bool mine = to_bsdf && kind == k;
+            const unsigned long long same = __ballot(mine);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&s_kind[k], (uint32_t)__popcll(same));
+            base = (uint32_t)__shfl((int)base, leader, 64);
+            if (mine) rank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            todo &= ~same;
         }
         __syncthreads();
-        if (threadIdx.x < 64) {         // exclusive prefix over the kinds, one per lane of the first wave
-            const uint32_t mine = s_kind[threadIdx.x];
-            uint32_t incl = mine;
+        // exclusive prefix over the kinds, computed by every wave for itself (lane l holds kind l): no second barrier
+        const uint32_t held = s_kind[lane];
+        uint32_t incl = held;
 #pragma unroll
-            for (int dlt = 1; dlt < 64; dlt <<= 1) {
-                uint32_t t = (uint32_t)__shfl_up((int)incl, dlt, 64);
-                if ((int)threadIdx.x >= dlt) incl += t;
-            }
-            s_kind[threadIdx.x] = incl - mine;
-            if (threadIdx.x == 63) w.bsdf_count[blockIdx.x] = incl;
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            uint32_t t = (uint32_t)__shfl_up((int)incl, dlt, 64);
+            if (lane >= dlt) incl += t;
         }
-        __syncthreads();
-        if (to_bsdf) w.bsdf_queue[(size_t)blockIdx.x * kBlock + s_kind[kind] + rank] = slot;
+        const uint32_t first = (uint32_t)__shfl((int)(incl - held), (int)kind, 64);
+        if (threadIdx.x == 63) w.bsdf_count[blockIdx.x] = incl;
+        if (to_bsdf) w.bsdf_queue[(size_t)blockIdx.x * kBlock + first + rank] = slot;
     }
+    SST(5);
+#if PT_STAMPS_SHADE
+    ssl[3] = (unsigned long long)__popcll(__ballot(finished));
+#endif
     finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples, false);
+    SST(6);
     if (live) {
         if (P.state == ST_AFTER) {
             // the bsdf stage reads the shadow direction from the ray arrays; mark the slot as having no ray to trace
@@ -695,6 +737,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE
         if (threadIdx.x == 0) w.chunk_rays[blockIdx.x] = nr;
     }
     if (__any(alive) && (threadIdx.x & 63u) == 0) w.counters[WF_CTR_LIVE] = 1u;     // a flag, not a count: plain store
+#if PT_STAMPS_SHADE
+    SST(7);
+    if ((threadIdx.x & 63u) == 0) {
+        // words: 0 waves, 1 loads, 2 resolve_hit, 3 shadow branch, 4 path branch (+ vertex store), 5 queue sort, 6 regenerate, 7 stores;
+        // 8 live lanes, 9 shadow lanes, 10 miss lanes, 11 finished lanes
+        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(w.counters + WF_CTR_WORDS);
+        atomicAdd(dbg + 0, 1ull); atomicAdd(dbg + 1, sst[1] - sst[0]); atomicAdd(dbg + 2, sst[2] - sst[1]); atomicAdd(dbg + 3, sst[3] - sst[2]);
+        atomicAdd(dbg + 4, sst[4] - sst[3]); atomicAdd(dbg + 5, sst[5] - sst[4]); atomicAdd(dbg + 6, sst[6] - sst[5]); atomicAdd(dbg + 7, sst[7] - sst[6]);
+        atomicAdd(dbg + 8, ssl[0]); atomicAdd(dbg + 9, ssl[1]); atomicAdd(dbg + 10, ssl[2]); atomicAdd(dbg + 11, ssl[3]);
+    }
+#endif
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
 
