@@ -39,6 +39,19 @@ def test_library_exports_every_declared_symbol():
     assert not undeclared, undeclared
 
 
+def test_binding_constants_equal_the_header():
+    """Every PT_* integer constant the Python binding carries has the header's value."""
+    text = open(os.path.join(ROOT, 'include', 'pt_capi.h')).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r'^#define\s+(PT_[A-Z0-9_]+)\s+\(?(-?(?:0x)?[0-9a-fA-F]+)\)?\s*(?:/\*.*)?$', text, flags=re.M)}
+    assert {'PT_BVH_REFERENCE', 'PT_BVH_GPU_LBVH', 'PT_BVH_GPU_LBVH_VIA_HOST', 'PT_BVH_GPU_PLOC', 'PT_NOALLOC_MAX_RAYS'} <= set(defs)
+    checked = 0
+    for name, value in defs.items():
+        if hasattr(lib, name):
+            assert getattr(lib, name) == value, name
+            checked += 1
+    assert checked >= 5
+
+
 def test_pod_layouts_match_the_reference_structs():
     """structs.cuh:111-181 sizes as nvcc lays them out: Triangle 112, BVH_Node 32, Material 176, kernelParams 152."""
     text = open(os.path.join(ROOT, 'include', 'pt_capi.h')).read()
