@@ -710,7 +710,7 @@ int pt_build_bvh(pt_ctx* c, int flavour)
         HIP_TRY(hipSetDevice(c->device));
         std::vector<int> new_idx((size_t)n);
         GpuScene g;
-        int rc = gpu_build_scene(c->d_tri_ref, n, c->leaf_merge, flavour == PT_BVH_GPU_PLOC, &g, new_idx.data(), c->stream);
+        int rc = gpu_build_scene(c->d_tri_ref, n, c->leaf_merge, flavour == PT_BVH_GPU_PLOC, flavour == PT_BVH_GPU_PLOC, &g, new_idx.data(), c->stream);
         if (rc != PT_OK) return rc;
         const int stack_capacity = 16 + 48      /* LDS entries + private spill entries of the traversal kernels */;
         if (g.stack_need_binary > stack_capacity) {

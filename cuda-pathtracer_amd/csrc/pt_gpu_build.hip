@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 #include "pt_internal.h"
@@ -265,6 +266,7 @@ __global__ __launch_bounds__(256) void gb_emit_tris(const pt_triangle* __restric
 // The trees come out close to a full SAH sweep's in traversal cost, at a few more passes over the data than the
 // radix tree. Everything is decided by running sums, not by atomics: the same input gives the same tree.
 constexpr int kPlocRadius = 16;
+constexpr int kTopNodes = 8191;         // nodes of the first levels that the host rebuilds with a surface-area sweep
 
 __global__ __launch_bounds__(256) void gb_ploc_init(const pt_triangle* __restrict__ tris, const uint32_t* __restrict__ ids, int n, int* __restrict__ cl_node, TightBox* __restrict__ cl_box)
 {
@@ -475,6 +477,120 @@ __global__ __launch_bounds__(256) void gb_wide_link(const int* __restrict__ it_d
     }
 }
 
+// ---------------------------------------------------------------- SAH over the top of the tree (host)
+// Morton-order builders decide the large-scale structure of the tree from a space-filling curve; a sweep over all
+// split planes does that part better. The first levels (a few thousand nodes in breadth-first order) are therefore
+// rebuilt on the host: their lowest children -- subtrees and single leaves -- become the items of a top-down build with
+// the full surface-area sweep on three axes, weighted by triangle counts. The subtrees below stay as the device made
+// them, and so does the order of the triangle records: no top node is ever tested as one leaf.
+struct TopItem { int ref; TightBox box; int count, height; };      // ref: as in DNode (>= 0: node position, < 0: leaf)
+
+static double item_area(const TightBox& b) { double x = (double)b.hi[0] - b.lo[0], y = (double)b.hi[1] - b.lo[1], z = (double)b.hi[2] - b.lo[2]; return x * y + y * z + z * x; }
+static TightBox item_join(const TightBox& a, const TightBox& b)
+{
+    TightBox u;
+    for (int k = 0; k < 3; k++) { u.lo[k] = std::fmin(a.lo[k], b.lo[k]); u.hi[k] = std::fmax(a.hi[k], b.hi[k]); }
+    return u;
+}
+
+struct TopBuilder {
+    std::vector<TopItem>& items;
+    std::vector<DNode>& nodes; std::vector<TightBox>& tl; std::vector<TightBox>& tr; std::vector<NodeAux>& aux;
+    int next_node = 0;
+    std::vector<double> suffix;
+    // builds the subtree over items[first, last) (at least two) into node `at`; returns its box, count and height
+    void build(int at, int first, int last, TightBox* box_out, int* count_out, int* height_out, int depth = 0)
+    {
+        const int n = last - first;
+        int best_axis = 0, best_split = first + n / 2;
+        double best_cost = INFINITY;
+        // (below 48 levels of lopsided splits the halves are taken by the median: the recursion stays shallow)
+        for (int axis = 0; axis < 3 && n > 2; axis++) {
+            std::sort(items.begin() + first, items.begin() + last, [axis](const TopItem& a, const TopItem& b) {
+                const float ca = a.box.lo[axis] + a.box.hi[axis], cb = b.box.lo[axis] + b.box.hi[axis];
+                return ca < cb || (ca == cb && a.ref < b.ref); });
+            suffix.assign((size_t)n + 1, 0.0);
+            TightBox acc = items[(size_t)last - 1].box; long long cnt = 0;
+            for (int i = last - 1; i > first; i--) { acc = item_join(acc, items[(size_t)i].box); cnt += items[(size_t)i].count; suffix[(size_t)(i - first)] = item_area(acc) * (double)cnt; }
+            acc = items[(size_t)first].box; cnt = 0;
+            for (int i = first; i < last - 1; i++) {
+                acc = item_join(acc, items[(size_t)i].box); cnt += items[(size_t)i].count;
+                const double cost = item_area(acc) * (double)cnt + suffix[(size_t)(i + 1 - first)];
+                if (cost < best_cost && (depth < 48 || axis == 0)) { best_cost = cost; best_axis = axis; best_split = depth < 48 ? i + 1 : first + n / 2; }
+            }
+        }
+        if (n > 2) {
+            const int axis = best_axis;
+            std::sort(items.begin() + first, items.begin() + last, [axis](const TopItem& a, const TopItem& b) {
+                const float ca = a.box.lo[axis] + a.box.hi[axis], cb = b.box.lo[axis] + b.box.hi[axis];
+                return ca < cb || (ca == cb && a.ref < b.ref); });
+        }
+        TightBox cb[2]; int cc[2], ch[2], cref[2];
+        const int lo[2] = {first, best_split}, hi[2] = {best_split, last};
+        for (int side = 0; side < 2; side++) {
+            if (hi[side] - lo[side] == 1) {
+                const TopItem& it = items[(size_t)lo[side]];
+                cref[side] = it.ref; cb[side] = it.box; cc[side] = it.count; ch[side] = it.height;
+            } else {
+                const int child = next_node++;
+                cref[side] = child;
+                build(child, lo[side], hi[side], &cb[side], &cc[side], &ch[side], depth + 1);
+            }
+        }
+        DNode d{};
+        for (int a = 0; a < 3; a++) { d.lmin[a] = cb[0].lo[a] - kPad; d.lmax[a] = cb[0].hi[a] + kPad; d.rmin[a] = cb[1].lo[a] - kPad; d.rmax[a] = cb[1].hi[a] + kPad; }
+        d.left = cref[0]; d.right = cref[1];
+        nodes[(size_t)at] = d; tl[(size_t)at] = cb[0]; tr[(size_t)at] = cb[1];
+        NodeAux me;
+        me.first = 0; me.count = cc[0] + cc[1]; me.height = 1 + (ch[0] > ch[1] ? ch[0] : ch[1]); me.mergeable = 0;
+        aux[(size_t)at] = me;
+        *box_out = item_join(cb[0], cb[1]); *count_out = me.count; *height_out = me.height;
+    }
+};
+
+// Rebuilds nodes [0, n_top) (whole breadth-first levels) in place. d_nodes, d_tl, d_tr, d_aux are indexed by node position.
+static int rebuild_top(DNode* d_nodes, TightBox* d_tl, TightBox* d_tr, NodeAux* d_aux, int n_top, int n_known, int min_count, hipStream_t stream)
+{
+#define GB_TRYR(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error("%s failed: %s", #x, hipGetErrorString(e_)); return PT_ERR_HIP; } } while (0)
+    std::vector<DNode> nodes((size_t)n_top);
+    std::vector<TightBox> tl((size_t)n_top), tr((size_t)n_top);
+    std::vector<NodeAux> aux((size_t)n_known);
+    GB_TRYR(hipMemcpyAsync(nodes.data(), d_nodes, nodes.size() * sizeof(DNode), hipMemcpyDeviceToHost, stream));
+    GB_TRYR(hipMemcpyAsync(tl.data(), d_tl, tl.size() * sizeof(TightBox), hipMemcpyDeviceToHost, stream));
+    GB_TRYR(hipMemcpyAsync(tr.data(), d_tr, tr.size() * sizeof(TightBox), hipMemcpyDeviceToHost, stream));
+    GB_TRYR(hipMemcpyAsync(aux.data(), d_aux, aux.size() * sizeof(NodeAux), hipMemcpyDeviceToHost, stream));
+    GB_TRYR(hipStreamSynchronize(stream));
+    std::vector<TopItem> items;
+    for (int p = 0; p < n_top; p++) {
+        const int ref[2] = {nodes[(size_t)p].left, nodes[(size_t)p].right};
+        const TightBox* box[2] = {&tl[(size_t)p], &tr[(size_t)p]};
+        for (int side = 0; side < 2; side++) {
+            if (ref[side] >= 0 && ref[side] < n_top) continue;         // a top node itself
+            if (ref[side] >= n_known) { set_error("rebuild_top: child %d of node %d lies beyond the known levels", ref[side], p); return PT_ERR_HIP; }
+            TopItem it;
+            it.ref = ref[side]; it.box = *box[side];
+            it.count = ref[side] < 0 ? 1 : aux[(size_t)ref[side]].count;
+            it.height = ref[side] < 0 ? 0 : aux[(size_t)ref[side]].height;
+            items.push_back(it);
+        }
+    }
+    if ((int)items.size() != n_top + 1) { set_error("rebuild_top: %d items under %d nodes", (int)items.size(), n_top); return PT_ERR_HIP; }
+    (void)min_count;
+    std::vector<NodeAux> top_aux((size_t)n_top);
+    TopBuilder tb{items, nodes, tl, tr, top_aux};
+    tb.next_node = 1;
+    TightBox rb; int rc_count = 0, rh = 0;
+    tb.build(0, 0, (int)items.size(), &rb, &rc_count, &rh);
+    if (tb.next_node != n_top) { set_error("rebuild_top: %d of %d nodes rebuilt", tb.next_node, n_top); return PT_ERR_HIP; }
+    GB_TRYR(hipMemcpyAsync(d_nodes, nodes.data(), nodes.size() * sizeof(DNode), hipMemcpyHostToDevice, stream));
+    GB_TRYR(hipMemcpyAsync(d_tl, tl.data(), tl.size() * sizeof(TightBox), hipMemcpyHostToDevice, stream));
+    GB_TRYR(hipMemcpyAsync(d_tr, tr.data(), tr.size() * sizeof(TightBox), hipMemcpyHostToDevice, stream));
+    GB_TRYR(hipMemcpyAsync(d_aux, top_aux.data(), top_aux.size() * sizeof(NodeAux), hipMemcpyHostToDevice, stream));
+    GB_TRYR(hipStreamSynchronize(stream));
+    return PT_OK;
+#undef GB_TRYR
+}
+
 } // namespace
 
 // tris_dev: n triangles on the device. nodes_dev: 2n-1 nodes, tri_idx_dev: n indices, both written here.
@@ -528,7 +644,7 @@ done:
 // tris_dev: n >= 2 triangles on the device. Builds the tree (the radix tree over the Morton order, or the agglomerative
 // tree over the same order) and every traversal layout on the device; tri_idx_host receives the triangle order of the
 // leaves (n entries).
-int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, bool agglomerative, GpuScene* out, int* tri_idx_host, hipStream_t stream)
+int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, bool agglomerative, bool top_sah, GpuScene* out, int* tri_idx_host, hipStream_t stream)
 {
     if (!tris_dev || n < 2 || !out || !tri_idx_host) { set_error("gpu_build_scene: bad argument"); return PT_ERR_ARG; }
     int rc = PT_OK;
@@ -588,7 +704,7 @@ int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, bool agg
             TightBox* cl_box[2] = {d_clbox, d_clbox + n};
             hipLaunchKernelGGL(gb_ploc_init, grid, block, 0, stream, tris_dev, d_ids_sorted, n, cl_node[0], cl_box[0]);
             int m = n, made = 0, cur = 0;
-            const int radius = getenv("PT_PLOC_RADIUS") ? atoi(getenv("PT_PLOC_RADIUS")) : kPlocRadius;
+            const int radius = kPlocRadius;
             for (int round = 0; m > 1; round++) {
                 if (round > 4096) { set_error("gpu_build_scene: the agglomerative build did not converge"); rc = PT_ERR_HIP; goto done; }
                 hipLaunchKernelGGL(gb_ploc_nearest, blocks(m), block, 0, stream, cl_box[cur], m, radius, nn);
@@ -671,6 +787,16 @@ int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, bool agg
             hipLaunchKernelGGL(gb_fit_level, blocks(cnt), block, 0, stream, tris_dev, d_ids_sorted, d_order, d_newid, left, right, lo, cnt, g.nodes, d_tl, d_tr, d_aux);
         }
         GB_TRY(hipGetLastError());
+        {
+            // the top of the tree: whole levels, as many as hold at most kTopNodes nodes, rebuilt with the surface-area sweep
+            const int top_limit = kTopNodes;
+            int levels = 0;
+            while (levels + 2 < (int)level_start.size() && level_start[(size_t)levels + 1] <= top_limit) levels++;
+            if (top_sah && levels >= 2) {
+                const int n_top = level_start[(size_t)levels], n_known = level_start[(size_t)levels + 1];
+                if ((rc = rebuild_top(g.nodes, d_tl, d_tr, d_aux, n_top, n_known, 0, stream)) != PT_OK) goto done;
+            }
+        }
         TightBox root_lr[2]; NodeAux root_aux; uint32_t misc[4];
         GB_TRY(hipMemcpyAsync(&root_lr[0], d_tl, sizeof(TightBox), hipMemcpyDeviceToHost, stream));
         GB_TRY(hipMemcpyAsync(&root_lr[1], d_tr, sizeof(TightBox), hipMemcpyDeviceToHost, stream));

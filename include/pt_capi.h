@@ -43,7 +43,7 @@ extern "C" {
 #define PT_BVH_REFERENCE 0   /* identical tree to BVH_builder.cpp:12-128, built with binned sweeps */
 #define PT_BVH_GPU_LBVH  1   /* pt_build_bvh only: Morton-order radix tree built on the GPU in milliseconds; same images (closest hits do not depend on the tree), different test counters */
 #define PT_BVH_GPU_LBVH_VIA_HOST 2   /* pt_build_bvh only: the same tree, copied to the host in the reference's node layout and taken in through pt_upload_bvh (cross-check of the device-side layouts) */
-#define PT_BVH_GPU_PLOC  3   /* pt_build_bvh only: agglomerative tree built on the GPU over the Morton order (clusters merge with their nearest neighbour within a window); a few times the build time of PT_BVH_GPU_LBVH, traversal cost close to the SAH tree's; same images */
+#define PT_BVH_GPU_PLOC  3   /* pt_build_bvh only: agglomerative tree built on the GPU over the Morton order (clusters merge with their nearest neighbour within a window), its first levels rebuilt on the host with a surface-area sweep; about the build time of PT_BVH_GPU_LBVH, traversal cost within a few percent of the SAH tree's; same images */
 
 typedef struct pt_float2 { float x, y; } pt_float2;
 typedef struct pt_float3 { float x, y, z; } pt_float3;
