@@ -45,6 +45,8 @@ void usage()
         "  --out FILE.png    displayed image (default out.png)    --pfm FILE.pfm   fp32 accumulator\n"
         "  --exr FILE.exr    linear radiance (accumulator / frames), 32-bit float OpenEXR\n"
         "  --resume FILE.pfm --resume-frames K   continue from a saved accumulator of K frames\n"
+        "  --tree KIND       host (the reference's surface-area builder, default), lbvh (radix tree built on the GPU) or\n"
+        "                    ploc (agglomerative tree built on the GPU, close to the host tree in traversal cost)\n"
         "  --gpu ID          device (default 0); with --gpus the first of the devices used\n"
         "  --gpus N          render on N GPUs: the scene goes to each, GPU r renders samples [r*spp/N, (r+1)*spp/N), and one\n"
         "                    RCCL reduce sums the accumulators onto the first GPU, which writes the outputs\n");
@@ -67,7 +69,7 @@ bool parse_floats(const char* s, float* out, int n)
 
 int main(int argc, char** argv)
 {
-    std::string obj, dir, subdir, hdr, out = "out.png", pfm, exr, resume;
+    std::string obj, dir, subdir, hdr, out = "out.png", pfm, exr, resume, tree = "host";
     int W = 1920, H = 1080, spp = 64, bounces = 512, gpu = 0, per_call = 0, resume_frames = 0, gpus = 1;
     float origin[3] = {0.f, 1.5f, 5.f}, angle[2] = {0.f, 0.f}, fov = 1.f, dof = 0.f, focal = 200.f, post[3] = {1.f, 1.f, 1.f};
     bool preview = false, sunsky = false, use_post = false, general = false;
@@ -87,6 +89,7 @@ int main(int argc, char** argv)
         else if (a == "--size") { if (std::sscanf(val(), "%dx%d", &W, &H) != 2) usage(); }
         else if (a == "--spp") spp = std::atoi(val());
         else if (a == "--bounces") bounces = std::atoi(val());
+        else if (a == "--tree") tree = val();
         else if (a == "--gpu") gpu = std::atoi(val());
         else if (a == "--gpus") gpus = std::atoi(val());
         else if (a == "--frames-per-call") per_call = std::atoi(val());
@@ -132,10 +135,14 @@ int main(int argc, char** argv)
     int n_tri = 0, n_mat = 0, n_tex = 0;
     must(pt_host_scene_counts(hs, &n_tri, &n_mat, &n_tex), "model");
     std::printf("model: %d triangles, %d materials, %d texture files (%.2f s)\n", n_tri, n_mat, n_tex, seconds());
-    std::vector<pt_bvh_node> nodes((size_t)2 * n_tri);
+    if (tree != "host" && tree != "lbvh" && tree != "ploc") usage();
+    std::vector<pt_bvh_node> nodes;
     int nodes_used = 0;
-    must(pt_host_build_bvh(pt_host_scene_triangles(hs), pt_host_scene_tri_idx(hs), n_tri, PT_BVH_REFERENCE, nodes.data(), &nodes_used), "BVH build");
-    std::printf("BVH: %d nodes (%.2f s)\n", nodes_used, seconds());
+    if (tree == "host") {
+        nodes.resize((size_t)2 * n_tri);
+        must(pt_host_build_bvh(pt_host_scene_triangles(hs), pt_host_scene_tri_idx(hs), n_tri, PT_BVH_REFERENCE, nodes.data(), &nodes_used), "BVH build");
+        std::printf("BVH: %d nodes (%.2f s)\n", nodes_used, seconds());
+    }
 
     // textures and the environment are decoded once, then every GPU gets the whole scene
     struct Tex { float* texels; int w, h, comps; };
@@ -164,7 +171,11 @@ int main(int argc, char** argv)
         }
         must(pt_upload_triangles(c, pt_host_scene_tri_idx(hs), pt_host_scene_triangles(hs), n_tri), "triangles");
         must(pt_upload_materials(c, pt_host_scene_materials(hs), n_mat), "materials");
-        must(pt_upload_bvh(c, nodes.data(), 0, nodes_used, n_tri), "BVH upload");
+        if (tree == "host") must(pt_upload_bvh(c, nodes.data(), 0, nodes_used, n_tri), "BVH upload");
+        else {
+            must(pt_build_bvh(c, tree == "ploc" ? PT_BVH_GPU_PLOC : PT_BVH_GPU_LBVH), "BVH build on the GPU");
+            if (g == 0) std::printf("BVH: built on the GPU (%s, %.2f s)\n", tree.c_str(), seconds());
+        }
         if (env_rgba) must(pt_upload_envmap(c, env_rgba, cdf.data(), ew, eh, env_sum, &P), "environment upload");
         must(pt_set_sky_mode(c, sunsky ? PT_SKY_SUNSKY : PT_SKY_ENVMAP), "sky mode");
         must(pt_set_max_bounces(c, bounces), "bounce cap");

@@ -217,6 +217,9 @@ def test_ten_million_triangle_soup():
     nodes, idx = lib.host_build_bvh(tris)
     r.upload_scene(tris, mats, idx, nodes)
     assert _same_hits(r.trace_closest_fast(rays), fast)
+    # and the agglomerative tree with its host-built top, at this size
+    r.upload_scene(tris, mats, None, None, flavour=lib.PT_BVH_GPU_PLOC)
+    assert _same_hits(r.trace_closest_fast(rays), fast)
     r.close()
     S = orc.Scene(tris, mats, idx, nodes)
     S.set_env(env4)

@@ -470,6 +470,12 @@ def test_headless_front_end_end_to_end(tmp_path):
     assert r.returncode == 0, r.stderr
     assert np.array_equal(bits(lib.load_pfm(pfm)), bits(want))
     assert np.array_equal(np.asarray(Image.open(png)), orc.resolve_display(want, 4))
+    # the trees built on the GPU give the same image
+    for tree in ('lbvh', 'ploc'):
+        r = subprocess.run(common + ['--spp', '4', '--tree', tree, '--out', png, '--pfm', pfm], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert 'built on the GPU' in r.stdout
+        assert np.array_equal(bits(lib.load_pfm(pfm)), bits(want)), tree
 
 
 @pytest.mark.parametrize('mode', MODES)
