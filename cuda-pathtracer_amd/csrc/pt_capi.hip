@@ -710,9 +710,17 @@ int pt_build_bvh(pt_ctx* c, int flavour)
         HIP_TRY(hipSetDevice(c->device));
         std::vector<int> new_idx((size_t)n);
         GpuScene g;
+        const int stack_capacity = 16 + 48      /* LDS entries + private spill entries of the traversal kernels */;
         int rc = gpu_build_scene(c->d_tri_ref, n, c->leaf_merge, flavour == PT_BVH_GPU_PLOC, flavour == PT_BVH_GPU_PLOC, &g, new_idx.data(), c->stream);
         if (rc != PT_OK) return rc;
-        const int stack_capacity = 16 + 48      /* LDS entries + private spill entries of the traversal kernels */;
+        if (flavour == PT_BVH_GPU_PLOC && g.stack_need_binary > stack_capacity) {
+            // an agglomerative tree can come out lopsided (clusters swallowing their neighbours one by one); the radix
+            // tree over the same order is bounded by the key length
+            (void)hipFree(g.nodes); (void)hipFree(g.qnodes); (void)hipFree(g.nodes4); (void)hipFree(g.tris);
+            g = GpuScene{};
+            rc = gpu_build_scene(c->d_tri_ref, n, c->leaf_merge, false, false, &g, new_idx.data(), c->stream);
+            if (rc != PT_OK) return rc;
+        }
         if (g.stack_need_binary > stack_capacity) {
             (void)hipFree(g.nodes); (void)hipFree(g.qnodes); (void)hipFree(g.nodes4); (void)hipFree(g.tris);
             set_error("pt_build_bvh: tree depth %d exceeds the traversal stack of %d entries", g.stack_need_binary, stack_capacity);
