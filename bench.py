@@ -295,7 +295,7 @@ def main():
                                   '(40 + 32 per box test + 48 per triangle test). '
                                   + ('The %.0f MB the walk touches are served from L2 / Infinity Cache,' % ((node_b + tri_b) / 1e6) + ' so this fraction measures cache gather rate against the HBM peak, not HBM use: traffic (PMC) is what reaches memory, '
                                      'and the kernel is bound by vector instruction issue (issue).' if args.workload != 'soup' else
-                                     'The %.1f GB of wide nodes and triangle records fit no cache: the node and triangle reads are random 64-byte HBM accesses; see traffic and issue.' % ((node_b + tri_b) / 1e9))),
+                                     'The %.1f GB of wide nodes and triangle records fit no cache: the node and triangle reads are random 64-byte accesses, of which the upper levels of the tree are served from the caches; see traffic and issue.' % ((node_b + tri_b) / 1e9))),
                          'whole_path_algorithmic_GBs': round(algorithmic_bytes(loc) / (elapsed * 1e9), 2)},
         }
 
