@@ -1,3 +1,4 @@
+"""Repeated tree builds on the device (radix and agglomerative flavours) must give the same tree: same walk counters, same node count."""
 import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'cuda-pathtracer_amd', 'python')); sys.path.insert(0, os.path.join(ROOT, 'tests'))

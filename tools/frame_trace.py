@@ -1,3 +1,4 @@
+"""Wall time of the first pt_render_frame calls of a view (ramp of the look-ahead batches)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, 'cuda-pathtracer_amd', 'python')); sys.path.insert(0, os.path.join(ROOT, 'tests'))

@@ -1,3 +1,4 @@
+"""Diagnostic: one ray through the production and the reference-order traversal, with the nodes each visits."""
 import sys; sys.path.insert(0,'cuda-pathtracer_amd/python'); sys.path.insert(0,'tests')
 import numpy as np, ptamd, util, orc
 from ptamd import scenes
