@@ -311,6 +311,13 @@ PT_DEV Hit closest_hit(const DScene& S, F3 o, F3 d, int tid, uint32_t& nbox, uin
     return best;
 }
 
+// The exit distance of a wide box is taken 2^-19 wider (relative) before it is compared with the entry distance. The
+// boxes' own margin is absolute (a fraction of the scene's largest coordinate), while the rounding of the plane
+// distances grows with the distance: the hardware reciprocals of two axes differ by up to 2^-22 of t, so for a ray that
+// starts many scene extents away a thin box (a flat floor seen from far above) would compute entry >= exit and be lost.
+// Near the surface the factor changes nothing (2^-19 of a small t), so thin boxes stay thin for rays that leave them.
+constexpr float kWideExitSlack = 1.0000019073486328f;
+
 // One step through a 4-wide node (DNode4: a grid origin, a power-of-two cell size per axis, four child boxes as
 // 8-bit grid coordinates, four child references): the entry distances of the four children, culled against the
 // bound `cull` (the best hit so far, taken a little wide), sorted nearest first (1e30 = not to be visited). A plane
@@ -341,7 +348,7 @@ PT_DEV void wide_step(const float4& n0, const float4& n1, const float4& n2, cons
         const float tnz = __builtin_fmaf((float)((az >> (8 * k)) & 255u), sz, bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 255u), sz, bz);
         const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
         const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
-        dk[k] = (tf > tn && tf > 0.f && tn < cull) ? tn : 1e30f;
+        dk[k] = (tf * kWideExitSlack > tn && tf > 0.f && tn < cull) ? tn : 1e30f;
     }
     d0 = dk[0]; d1 = dk[1]; d2 = dk[2]; d3 = dk[3];       // (a missing child's slabs are inverted: never entered)
     auto cswap = [](float& da, int& ra, float& db, int& rb) {

@@ -488,7 +488,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                 const float tnz = __builtin_fmaf((float)((az >> (8 * k)) & 255u), sz, bz), tfz = __builtin_fmaf((float)((fz >> (8 * k)) & 255u), sz, bz);
                 const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), tnz);
                 const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), tfz);
-                dk[k] = (tf > tn && tf > 0.f && tn < cull) ? tn : 1e30f;
+                dk[k] = (tf * kWideExitSlack > tn && tf > 0.f && tn < cull) ? tn : 1e30f;
             }
             float d0 = dk[0], d1 = dk[1], d2 = dk[2], d3 = dk[3];       // (a missing child's slabs are inverted: never entered)
             auto cswap = [](float& da, int& ra, float& db, int& rb) {

@@ -349,6 +349,68 @@ def test_production_traversal_kernel_matches_brute_force():
     r.close()
 
 
+def _flat_floor(n, extent):
+    """An n x n grid of quads (2 n^2 triangles) in the plane z = 0 over [-extent, extent]^2."""
+    from ptamd.types import TRI_DTYPE
+    xs = np.linspace(-extent, extent, n + 1, dtype=np.float32)
+    x0, y0 = np.meshgrid(xs[:-1], xs[:-1], indexing='ij')
+    x1, y1 = np.meshgrid(xs[1:], xs[1:], indexing='ij')
+    z = np.zeros(n * n, np.float32)
+    p00 = np.stack([x0.ravel(), y0.ravel(), z], -1); p10 = np.stack([x1.ravel(), y0.ravel(), z], -1)
+    p01 = np.stack([x0.ravel(), y1.ravel(), z], -1); p11 = np.stack([x1.ravel(), y1.ravel(), z], -1)
+    tris = np.zeros(2 * n * n, dtype=TRI_DTYPE)
+    tris['a'][0::2] = p00; tris['b'][0::2] = p10; tris['c'][0::2] = p11
+    tris['a'][1::2] = p00; tris['b'][1::2] = p11; tris['c'][1::2] = p01
+    for k in ('nA', 'nB', 'nC'):
+        tris[k] = [0.0, 0.0, 1.0]
+    return tris
+
+
+@pytest.mark.parametrize('extent', [1.0, 700.0])
+def test_thin_boxes_seen_from_far_away(extent):
+    """The wide boxes of a flat floor are a few rounding errors thick, while the rounding of a ray's plane distances
+    grows with the distance travelled: from 50, 100 and 1000 scene extents away entry and exit of such a box round to
+    the same number. The production kernel must still reach the triangles (the hits of exhaustive search), for rays straight down the axis and for oblique ones."""
+    tris = _flat_floor(8, extent)
+    b = util.Bundle(tris, ptamd.default_materials(1))
+    rng = np.random.default_rng(41)
+    from ptamd.types import RAY_DTYPE
+    parts = []
+    for far in (2.0, 50.0, 100.0, 1000.0, 30000.0):
+        n = 4000
+        rays = np.zeros(n, dtype=RAY_DTYPE)
+        target = np.zeros((n, 3), np.float32)
+        target[:, :2] = rng.uniform(-extent, extent, (n, 2))
+        o = target.copy()
+        o[:, 2] = far * extent
+        # a third straight down, a third oblique from above, a third from far off to the side at a grazing angle
+        o[n // 3:2 * n // 3, :2] += rng.uniform(-far * extent, far * extent, (n // 3, 2)).astype(np.float32)
+        # (grazing rays only up to 100 extents: further out the triangle test's own rounding, o - a at 10^6 units against
+        # edges of a quarter unit, accepts triangles the ray passes a sixth of an edge away from, and exact-t ties with
+        # such neighbours are beyond what any box can promise, the reference's padded ones included)
+        o[2 * n // 3:, 0] += min(far, 100.0) * extent * 40.0
+        d = target.astype(np.float64) - o.astype(np.float64)
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d[:n // 3] = [0.0, 0.0, -1.0]
+        rays['o'] = o; rays['d'] = d
+        parts.append(rays)
+    rays = np.concatenate(parts)
+    r = b.renderer(ptamd.default_params(64, 64))
+    fast = r.trace_closest_fast(rays)
+    brute = orc.closest_brute(b.oracle(), rays)
+    assert (brute['tri'] != 0xFFFFFFFF).mean() > 0.6
+    # (the reference-order walk is not held to this: boxIntersectF itself drops a box whose padded slab, 0.2 units,
+    # falls below one ulp of t, intersectors.cuh:59-71, so the reference loses these hits from 10^7 units away)
+    lost = (fast['tri'] != brute['tri']) | (bits(fast['t']) != bits(brute['t']))
+    assert not lost.any(), 'production walk differs on %d rays, first origin %r' % (lost.sum(), rays['o'][lost][0])
+    # the same floor through the trees built on the device (their wide boxes carry the same margin)
+    for flavour in (lib.PT_BVH_GPU_LBVH, lib.PT_BVH_GPU_PLOC):
+        r.upload_scene(b.tris, b.mats, None, None, flavour=flavour)
+        alt = r.trace_closest_fast(rays)
+        assert np.array_equal(alt['tri'], brute['tri']) and np.array_equal(bits(alt['t']), bits(brute['t'])), flavour
+    r.close()
+
+
 def test_committed_golden_vectors():
     """The HIP path against tests/golden/vectors.npz (no oracle run involved)."""
     import os
