@@ -316,7 +316,10 @@ PT_DEV Hit closest_hit(const DScene& S, F3 o, F3 d, int tid, uint32_t& nbox, uin
 // distances grows with the distance: the hardware reciprocals of two axes differ by up to 2^-22 of t, so for a ray that
 // starts many scene extents away a thin box (a flat floor seen from far above) would compute entry >= exit and be lost.
 // Near the surface the factor changes nothing (2^-19 of a small t), so thin boxes stay thin for rays that leave them.
-constexpr float kWideExitSlack = 1.0000019073486328f;
+#ifndef PT_WIDE_EXIT_SLACK
+#define PT_WIDE_EXIT_SLACK 1.0000019073486328f
+#endif
+constexpr float kWideExitSlack = PT_WIDE_EXIT_SLACK;
 
 // One step through a 4-wide node (DNode4: a grid origin, a power-of-two cell size per axis, four child boxes as
 // 8-bit grid coordinates, four child references): the entry distances of the four children, culled against the
