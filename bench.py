@@ -61,7 +61,6 @@ def main():
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl is RCCL; gloo lets several ranks rehearse on one GPU)')
     ap.add_argument('--device', type=int, default=-1, help='GPU to use (default: LOCAL_RANK)')
     ap.add_argument('--fp32-textures', action='store_true', help='keep 8-bit textures as fp32 texels instead of bytes')
-    ap.add_argument('--repack', type=int, default=-1, help='repack threshold in percent of the pool (0 = never, -1 = library default)')
     ap.add_argument('--env-guides', type=int, default=1, help='environment CDF search: 1 all guide tables, 2 without the whole-range table, 0 plain bisections')
     ap.add_argument('--lanes', type=int, default=0, help='concurrent wavefront lanes (0 = library default)')
     ap.add_argument('--drain', type=int, default=-1, help='finish the last paths in one kernel once at most this many remain (-1 = library default, 0 = never)')
@@ -147,8 +146,6 @@ def main():
         r.set_drain(args.drain)
     if args.lanes:
         r.set_lanes(args.lanes)
-    if args.repack >= 0:
-        r.set_repack(args.repack)
     if args.env_guides != 1:
         r.set_env_guides(args.env_guides)
     if args.tune:

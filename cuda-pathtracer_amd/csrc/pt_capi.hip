@@ -137,9 +137,11 @@ struct pt_ctx {
         WfParams w{};
         int batch = 8;
         bool finished = true;
-        size_t pool_slots = 0;          // slots each of the block's two pools has room for
-        int pool_side = 0;              // which of the two pools w points into
+        WfPathQueue path_q[2];          // the two buffers of each queue: an iteration reads one and appends to the other
+        WfShadowQueue shadow_q[2];
+        int parity = 0;                 // which buffers the next iteration reads
         bool all_started = false;       // the host has seen every sample id handed out to some workgroup
+        bool flushed = false;           // the ids workgroups still held then have been started (or there were none)
         uint64_t issued = 0, issue_cap = 0;   // stage iterations issued for the current chunk, and the most it can need
     };
     static constexpr int kMaxLanes = 2;
@@ -161,8 +163,7 @@ struct pt_ctx {
     } ahead;
     void* static_scratch = nullptr; // this device's copy of the library's built-in block (pt_trace_closest_noalloc_dev)
     hipError_t static_scratch_error = hipSuccess;
-    uint64_t wf_iterations = 0, wf_repacks = 0;
-    int repack_percent = 50;        // repack the pool when the live slots are at most this share of it (0: never)
+    uint64_t wf_iterations = 0, wf_drains = 0;
     bool stage_timing = false;
     double extend_ms = 0.0;
     uint64_t extend_launches = 0;
@@ -1003,35 +1004,54 @@ static int lane_counters(pt_ctx::WfLane& L)
     return PT_OK;
 }
 
-// Bytes of one slot pool of `slots` slots (a multiple of 256): 13 arrays of 16 bytes per slot, the bsdf queue,
-// and the per-block words (queue counts, sample chunks, ray counts, ray block list).
-static size_t pool_bytes(size_t slots)
+// Workgroups of a stage launch for a pool of `slots` samples in flight: enough to fill the GPU with the lightest
+// stage kernel, and no more than the pool has 256-record segments.
+static int stage_blocks_for(const pt_ctx* c, size_t slots)
 {
-    size_t b = slots * (13 * sizeof(float4) + sizeof(uint32_t)) + (slots / 256) * 5 * sizeof(uint32_t);
+    size_t b = (size_t)8 * (size_t)c->n_cus, segs = slots / 256;
+    if (segs < 1) segs = 1;
+    return (int)(b < segs ? b : segs);
+}
+
+// Entries every queue array gets for `slots` samples in flight: the pool itself plus the sample ids the stage
+// workgroups can hold in their chunks when the global hand-out runs dry (they are all started at once then).
+static size_t queue_capacity(const pt_ctx* c, size_t slots) { return slots + (size_t)stage_blocks_for(c, slots) * 256; }
+
+// Bytes of a lane's queues: 32 arrays of 16 bytes per entry (two buffers each of the path queue's 3 and the shadow
+// queue's 12, and the two hit arrays), the bsdf list, and the workgroups' sample-id chunks.
+static size_t pool_bytes(size_t capacity, int stage_blocks)
+{
+    size_t b = capacity * (32 * sizeof(float4) + sizeof(uint32_t)) + (size_t)stage_blocks * 2 * sizeof(uint32_t);
     return (b + 255) / 256 * 256;
 }
 
-// Points w's slot arrays into the pool that starts at `base`.
-static void pool_layout(pt_ctx* c, pt_ctx::WfLane& L, void* base_ptr, size_t slots, WfParams* w)
+// Points the lane's queue arrays into the block that starts at `base_ptr`.
+static void pool_layout(pt_ctx::WfLane& L, void* base_ptr, size_t capacity, int stage_blocks, WfParams* w)
 {
-    float4* base = (float4*)base_ptr;
-    float4** arrays[13] = {&w->ray_o, &w->ray_d, &w->hit, &w->c0, &w->c1, &w->c2, &w->d0, &w->d1, &w->e0, &w->e1, &w->e2, &w->e3, &w->e4};
-    for (int i = 0; i < 13; i++) *arrays[i] = base + (size_t)i * slots;
-    w->bsdf_queue = (uint32_t*)(base + (size_t)13 * slots);
-    w->bsdf_count = w->bsdf_queue + slots;
-    w->block_chunk = w->bsdf_count + slots / 256;
-    w->chunk_rays = w->block_chunk + 2 * (slots / 256);
-    w->chunk_list = w->chunk_rays + slots / 256;
+    float4* p = (float4*)base_ptr;
+    auto take = [&]() { float4* r = p; p += capacity; return r; };
+    for (int k = 0; k < 2; k++) {
+        WfPathQueue& P = L.path_q[k];
+        P.c0 = take(); P.c1 = take(); P.c2 = take();
+        WfShadowQueue& S = L.shadow_q[k];
+        S.so = take(); S.sd = take(); S.c0 = take(); S.c1 = take(); S.c2 = take(); S.d0 = take(); S.d1 = take();
+        S.e0 = take(); S.e1 = take(); S.e2 = take(); S.e3 = take(); S.e4 = take();
+    }
+    w->hitP = take(); w->hitS = take();
+    w->bsdf_list = (uint32_t*)p;
+    w->wg_chunk = w->bsdf_list + capacity;
     w->counters = L.counters;
-    w->n_slots = (int)slots;
+    w->capacity = (int)capacity;
+    w->stage_blocks = stage_blocks;
+    w->Pc = L.path_q[0]; w->Pn = L.path_q[1]; w->Sc = L.shadow_q[0]; w->Sn = L.shadow_q[1];
 }
 
-// Lays the slot arrays of a lane out in its block (grown if needed) for `slots` slots. The block holds two
-// pools of that size: the second one receives the live slots when the pool is repacked (and the first one
-// when it is repacked again).
+// Lays the queue arrays of a lane out in its block (grown if needed) for `slots` samples in flight.
 static int lane_pool(pt_ctx* c, pt_ctx::WfLane& L, size_t slots, WfParams* w)
 {
-    size_t need = 2 * pool_bytes(slots);
+    const int stage_blocks = stage_blocks_for(c, slots);
+    const size_t capacity = queue_capacity(c, slots);
+    size_t need = pool_bytes(capacity, stage_blocks);
     if (need > L.block_bytes) {
         if (L.block) { (void)hipFree(L.block); L.block = nullptr; L.block_bytes = 0; }
         HIP_TRY(hipMalloc(&L.block, need));
@@ -1039,30 +1059,31 @@ static int lane_pool(pt_ctx* c, pt_ctx::WfLane& L, size_t slots, WfParams* w)
     }
     int rc = lane_counters(L);
     if (rc != PT_OK) return rc;
-    L.pool_slots = slots;
-    L.pool_side = 0;
-    pool_layout(c, L, L.block, slots, w);
+    pool_layout(L, L.block, capacity, stage_blocks, w);
+    w->n_slots = (int)slots;
     w->refill_lanes = c->refill_lanes; w->leaf_vote = c->leaf_vote;
     w->count_wide = c->counting == 2 ? 1 : 0;
     w->extend_blocks = (c->extend_blocks_per_cu ? c->extend_blocks_per_cu : 5) * c->n_cus;
     return PT_OK;
 }
 
-// Moves the lane's live slots to the front of its other pool, sized for `live_bound` slots (an upper bound
-// of the live count), and makes that pool the current one.
-static int lane_repack(pt_ctx* c, pt_ctx::WfLane& L, uint32_t live_bound)
+// The lane's parameters as the iteration that comes next sees them: it reads the buffers `parity` names and
+// appends to the other ones.
+static WfParams lane_view(const pt_ctx::WfLane& L)
 {
-    size_t slots = ((size_t)live_bound + 255) / 256 * 256;
-    if (slots < 256) slots = 256;
-    WfParams dst = L.w;
-    int side = 1 - L.pool_side;
-    pool_layout(c, L, (char*)L.block + (size_t)side * pool_bytes(L.pool_slots), slots, &dst);
-    launch_wf_repack(L.w, dst, L.stream);
-    HIP_TRY(hipGetLastError());
-    L.w = dst;
-    L.pool_side = side;
-    c->wf_repacks++;
-    return PT_OK;
+    WfParams v = L.w;
+    v.Pc = L.path_q[L.parity]; v.Pn = L.path_q[L.parity ^ 1];
+    v.Sc = L.shadow_q[L.parity]; v.Sn = L.shadow_q[L.parity ^ 1];
+    return v;
+}
+// ... and as a kernel that appends to the queue that iteration will read sees them (the first samples, the
+// leftover ids)
+static WfParams lane_feed_view(const pt_ctx::WfLane& L)
+{
+    WfParams v = L.w;
+    v.Pc = L.path_q[L.parity ^ 1]; v.Pn = L.path_q[L.parity];
+    v.Sc = L.shadow_q[L.parity ^ 1]; v.Sn = L.shadow_q[L.parity];
+    return v;
 }
 
 // Sizes a lane's slot pool and staging array for `frames` frames of the pixels dealt to lane `lane` of `n_lanes`.
@@ -1103,8 +1124,15 @@ static const int kMaxBatch = 8;
 static int lane_issue_batch(pt_ctx* c, pt_ctx::WfLane& L, const DCamera& cam, DCounters* ctr)
 {
     if (c->stage_timing && !L.st_ev[0]) { for (int i = 0; i < 2 * kMaxBatch; i++) HIP_TRY(hipEventCreate(&L.st_ev[i])); }
-    for (int i = 0; i < L.batch; i++)
-        launch_wf_iteration(L.w, c->scene, cam, ctr, L.stream, c->stage_timing ? L.st_ev[2 * i] : nullptr, c->stage_timing ? L.st_ev[2 * i + 1] : nullptr);
+    if (L.all_started && !L.flushed) {
+        // the global hand-out has run dry: start the ids workgroups still hold in their chunks, all at once
+        launch_wf_flush_leftover(lane_feed_view(L), cam, ctr, L.stream);
+        L.flushed = true;
+    }
+    for (int i = 0; i < L.batch; i++) {
+        launch_wf_iteration(lane_view(L), c->scene, cam, ctr, L.stream, c->stage_timing ? L.st_ev[2 * i] : nullptr, c->stage_timing ? L.st_ev[2 * i + 1] : nullptr);
+        L.parity ^= 1;
+    }
     HIP_TRY(hipGetLastError());
     c->wf_iterations += L.batch;
     L.issued += (uint64_t)L.batch;
@@ -1170,11 +1198,16 @@ static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1
             if (rc != PT_OK) return rc;
             L.w.frame_begin = b;
             HIP_TRY(hipMemsetAsync(L.counters, 0, WF_CTR_WORDS * sizeof(uint32_t), L.stream));
-            launch_wf_generate(L.w, cam, ctr, L.stream);
+            HIP_TRY(hipMemsetAsync(L.w.wg_chunk, 0, (size_t)L.w.stage_blocks * 2 * sizeof(uint32_t), L.stream));
+            L.parity = 0;
+            launch_wf_generate(lane_feed_view(L), cam, ctr, L.stream);
             HIP_TRY(hipGetLastError());
-            L.batch = (size_t)L.w.n_slots >= (size_t)L.w.n_samples ? 2 : kMaxBatch;
+            // a pool that holds every sample of the chunk starts them all here: nothing is left to hand out
+            const bool all_at_once = (size_t)L.w.n_slots >= (size_t)L.w.n_samples;
+            L.batch = all_at_once ? 2 : kMaxBatch;
             L.finished = false;
-            L.all_started = false;
+            L.all_started = all_at_once;
+            L.flushed = all_at_once;
             // A sample visits at most (bounce cap + 1) vertices, each at most one path ray, one light sample of up to 32
             // visibility segments (pathtracer.cu:279) and one bsdf stage; a slot runs its share of the samples one after
             // the other. A loop that passes this bound is not going to end (a slot that keeps looking live): stop with
@@ -1193,24 +1226,20 @@ static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1
                     for (int k = 0; k < L.batch; k++) { float ms = 0.f; if (hipEventElapsedTime(&ms, L.st_ev[2 * k], L.st_ev[2 * k + 1]) == hipSuccess) { c->extend_ms += ms; c->extend_launches++; } }
                 }
                 const uint32_t* hc = L.host_counters;
-                // The counters of the planning pass (rays, leftover ids) are older than the last iteration of the
-                // batch: they bound what is in the pool now only if no workgroup could take new ids meanwhile,
-                // that is if the global cursor had run out before the batch was issued.
-                const bool settled = L.all_started;
+                // what the last iteration of the batch left in the queues it appended to
+                const uint64_t live = (uint64_t)hc[WF_CTR_TAIL_P] + (uint64_t)hc[WF_CTR_TAIL_S];
+                // Nothing more can start once the global hand-out had run dry before the batch was issued and the
+                // batch began by starting the ids the workgroups still held.
+                const bool settled = L.flushed;
                 if (hc[WF_CTR_NEXT_SAMPLE] >= L.w.n_samples) { L.batch = 2; L.all_started = true; }
-                bool done = hc[WF_CTR_LIVE] == 0;
-                // all sample ids handed out and few paths left: finish them in one kernel instead of one stage
+                bool done = settled && live == 0;
+                // every sample started and few paths left: finish them in one kernel instead of one stage
                 // launch sequence per remaining path vertex
-                if (!done && c->drain_rays > 0 && hc[WF_CTR_NEXT_SAMPLE] >= L.w.n_samples && hc[WF_CTR_RAYS] <= (uint32_t)c->drain_rays) {
-                    launch_wf_drain(L.w, c->scene, cam, (int)hc[WF_CTR_RAYS], ctr, L.stream);
+                if (!done && settled && c->drain_rays > 0 && live <= (uint64_t)c->drain_rays) {
+                    launch_wf_drain(lane_view(L), c->scene, cam, (int)live, ctr, L.stream);
                     HIP_TRY(hipGetLastError());
+                    c->wf_drains++;
                     done = true;
-                }
-                // all sample ids started and the pool mostly empty: move the live slots together
-                if (!done && c->repack_percent > 0 && settled && hc[WF_CTR_LEFTOVER] == 0 &&
-                    (uint64_t)hc[WF_CTR_RAYS] * 100u <= (uint64_t)L.w.n_slots * (uint64_t)c->repack_percent && L.w.n_slots > 256) {
-                    int rc = lane_repack(c, L, hc[WF_CTR_RAYS]);
-                    if (rc != PT_OK) return rc;
                 }
                 if (!done && L.issued > L.issue_cap) {
                     set_error("render: lane %d still has live paths after %llu stage iterations (bound %llu)", i, (unsigned long long)L.issued, (unsigned long long)L.issue_cap);
@@ -1262,18 +1291,11 @@ int pt_debug_words(pt_ctx* c, unsigned long long* out16)
     return PT_OK;
 }
 
-int pt_set_repack(pt_ctx* c, int percent)
-{
-    if (!c || percent < 0 || percent > 100) { set_error("pt_set_repack: bad argument"); return PT_ERR_ARG; }
-    c->repack_percent = percent;
-    return PT_OK;
-}
-
-int pt_wavefront_stats(pt_ctx* c, uint64_t* iterations_out, uint64_t* repacks_out)
+int pt_wavefront_stats(pt_ctx* c, uint64_t* iterations_out, uint64_t* drains_out)
 {
     if (!c) { set_error("null context"); return PT_ERR_ARG; }
     if (iterations_out) *iterations_out = c->wf_iterations;
-    if (repacks_out) *repacks_out = c->wf_repacks;
+    if (drains_out) *drains_out = c->wf_drains;
     return PT_OK;
 }
 
@@ -1585,11 +1607,12 @@ int pt_trace_closest_fast_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* 
     if (rc != PT_OK) return rc;
     if (n <= 0 || !rays_dev || !hits_dev) { set_error("pt_trace_closest_fast_dev: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
-    // borrow lane 0's ray and hit arrays
+    // borrow lane 0's queue arrays: the batch is a shadow queue of n pending rays
     size_t slots = ((size_t)n + 255) / 256 * 256;
     WfParams w{};
     rc = lane_pool(c, c->lanes[0], slots, &w);
     if (rc != PT_OK) return rc;
+    HIP_TRY(hipMemsetAsync(w.counters, 0, WF_CTR_WORDS * sizeof(uint32_t), c->stream));
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
     launch_wf_trace(w, c->scene, rays_dev, n, hits_dev, c->stream);
     HIP_TRY(hipGetLastError());

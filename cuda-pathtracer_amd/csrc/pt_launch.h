@@ -10,7 +10,7 @@ void launch_resolve_display(const float* accum_dev, int n_pixels, int n_frames, 
 void launch_post_process(const uint8_t* in_dev, int n_pixels, float exposure, const float* mult3, float saturation, float gamma, uint8_t* out_dev, hipStream_t stream);
 void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, hipStream_t s);
 void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t ext0, hipEvent_t ext1);
-void launch_wf_repack(const WfParams& src, const WfParams& dst, hipStream_t s);
+void launch_wf_flush_leftover(const WfParams& w, const DCamera& cam, DCounters* ctr, hipStream_t s);
 void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int max_paths, DCounters* ctr, hipStream_t s);
 void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, int first, int count, hipStream_t s);
 void launch_wf_trace(const WfParams& w, const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, hipStream_t s);

@@ -117,32 +117,50 @@ struct DCounters {
     unsigned long long rays, samples, box_tests, tri_tests, shade_vertices, env_samples, tex_taps, tex_taps_r;
 };
 
-// ---------------------------------------------------------------- wavefront pool
-// Path slots as a structure of 16-byte arrays (slot-indexed) plus the per-sample staging values.
-// device counters of the wavefront loop (one 32-bit word each)
+// ---------------------------------------------------------------- wavefront queues
+// A sample in flight is one record in one of two queues, by what it waits for: the closest hit of its path ray
+// (path queue, 48 bytes) or of a segment of the visibility walk of its light sample (shadow queue, 192 bytes: the
+// path state, the light sample and the vertex the walk started from). Both are structures of 16-byte arrays indexed
+// by queue position, and both are dense: every stage reads the current queues front to back and appends what it
+// produces to the next ones (positions handed out by one atomic per workgroup and queue), so a wave's 64 records
+// are consecutive and of one kind whatever the paths did before.
+struct WfPathQueue { float4 *c0, *c1, *c2; };                  // (o, thr) (d, pdf) (result, flags + bounce, draws, sample id)
+struct WfShadowQueue {
+    float4 *so, *sd;                // pending segment of the visibility walk; sd.w != 0 while the record waits for its hit
+    float4 *c0, *c1, *c2;           // path state as in the path queue (o is the vertex position)
+    float4 *d0, *d1;                // (transmittance so far, light pdf) (light radiance, 0)
+    float4 *e0, *e1, *e2, *e3, *e4; // vertex context: material values and shading normal
+};
+
+// Device counters of the wavefront loop, one 32-bit word each. The words that take atomics from every workgroup
+// of a launch sit 256 bytes apart: atomics on one cache line are served one after the other.
 enum : int {
-    WF_CTR_NEXT_SAMPLE = 0,   // next sample id the global hand-out gives to a workgroup (in chunks)
-    WF_CTR_LIVE = 2,          // set by the shade stage when any slot still carries a path
-    WF_CTR_RAY_NEXT = 4,      // next entry of chunk_list the extend kernel hands to a wave
-    WF_CTR_RAY_CHUNKS = 5,    // entries in chunk_list
-    WF_CTR_RAYS = 6,          // rays waiting at the last planning pass
-    WF_CTR_LEFTOVER = 7,      // sample ids workgroups still hold in their chunks at the last planning pass
-    WF_CTR_WORDS = 8
+    WF_CTR_NEXT_SAMPLE = 0,     // next sample id the global hand-out gives to a workgroup (in chunks)
+    WF_CTR_TAIL_P = 64,         // entries appended to the next path queue so far
+    WF_CTR_TAIL_S = 128,        // entries appended to the next shadow queue so far
+    WF_CTR_TAIL_B = 192,        // entries of the bsdf list
+    WF_CTR_RAY_NEXT = 256,      // next block of 256 rays the extend kernel hands to a wave
+    WF_CTR_SEG_PATH = 320,      // next 256-record segment of the current path queue / shadow queue / bsdf list a
+    WF_CTR_SEG_SHADOW = 384,    //   workgroup of the stage kernel takes
+    WF_CTR_SEG_BSDF = 448,
+    WF_CTR_N_P = 512,           // records in the current path queue and shadow queue (set by the planning pass)
+    WF_CTR_N_S = 513,
+    WF_CTR_RAY_CHUNKS = 514,    // blocks of 256 rays in both queues together; the first RAY_P_CHUNKS are path rays
+    WF_CTR_RAY_P_CHUNKS = 515,
+    WF_CTR_LEFTOVER = 516,      // sample ids workgroups still hold in their chunks at the last planning pass
+    WF_CTR_WORDS = 520
 };
 struct WfParams {
-    float4 *ray_o, *ray_d;          // pending ray; ray_d.w != 0 when the slot has a ray to trace
-    float4 *hit;                    // (t, triangle, u, v)
-    float4 *c0, *c1, *c2;           // (o, thr) (d, pdf) (result, flags, draws, sample id)
-    float4 *d0, *d1;                // (transmittance, light pdf) (light radiance, bounce)
-    float4 *e0, *e1, *e2, *e3, *e4; // vertex context: material values and shading normal
-    uint32_t* bsdf_queue;           // [n_slots], one 256-entry segment per workgroup
-    uint32_t* bsdf_count;           // [n_slots/256] entries used in each segment
-    uint32_t* block_chunk;          // [n_slots/256][2] cursor/end of the sample-id chunk each workgroup owns
-    uint32_t* chunk_rays;           // [n_slots/256] rays waiting in each block of 256 slots (written by the stages that make rays)
-    uint32_t* chunk_list;           // [n_slots/256] blocks with at least one ray, compacted before each extend launch
+    WfPathQueue Pc, Pn;             // current and next path queue
+    WfShadowQueue Sc, Sn;           // current and next shadow queue
+    float4 *hitP, *hitS;            // (t, triangle, u, v) for the records of the current queues
+    uint32_t* bsdf_list;            // positions in the current shadow queue (bit 31 set: in the next one) whose light sample is finished
+    uint32_t* wg_chunk;             // [stage_blocks][2] cursor/end of the sample-id chunk each persistent workgroup owns
     uint32_t* counters;
     float* staging;                 // n_frames * W * H sample values of the current chunk
-    int n_slots;
+    int capacity;                   // entries every queue array has room for (a multiple of 256)
+    int n_slots;                    // samples in flight at most (before the workgroups' leftover ids are started)
+    int stage_blocks;               // workgroups of a stage launch
     uint32_t n_samples;
     int W, H, tiled, frame_begin, n_frames;
     // The pixels of the image, in sample order (8x8 tiles when the size allows, else rows), are dealt to the lanes in

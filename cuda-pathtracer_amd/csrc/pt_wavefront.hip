@@ -1,22 +1,30 @@
 // Wavefront form of the render path: the per-sample state machine of pt_path.hpp cut into stage
-// kernels over a pool of path slots that live in HBM.
+// kernels over two dense queues of sample records that live in HBM.
 //
-//   generate : every slot takes a sample id and builds its camera ray
-//   plan     : one workgroup lists the 256-slot blocks that hold rays (empty blocks then cost nothing)
-//   extend   : closest hit for the pending ray of every live slot (camera, bounce and shadow-walk
+//   generate : the first samples: camera rays appended to the path queue
+//   plan     : one small workgroup turns the tails of the queues the stages appended to into the sizes of the
+//              current ones and resets the per-iteration counters
+//   extend   : closest hit for the pending ray of every record of both queues (camera, bounce and shadow-walk
 //              rays alike): persistent waves over 4-wide quantized nodes, traversal stack in LDS
-//   shade    : consumes the hit (material resolve, medium/surface event, light-sample set-up, shadow
-//              segment bookkeeping); slots whose vertex is ready to pick its next direction are
-//              compacted into their workgroup's segment of the bsdf queue
-//   bsdf     : Disney evaluation for the light sample, direction sampling, roulette (the fat,
-//              divergent code), run only over the compacted queue
+//   path     : consumes the hits of the path queue: miss (environment, sample finished) or vertex (material
+//              resolve, emission, medium / surface event, light-sample set-up); a vertex that drew a light sample
+//              moves to the next shadow queue, a ray that passed through to the next path queue
+//   shadow   : consumes the hits of the shadow queue, one segment of the visibility walk each (the light-weight
+//              kernel: alpha, metallic, transmission, ior and the medium of the surface it hit); a walk that goes
+//              on moves to the next shadow queue, a finished one is listed for the bsdf stage
+//   bsdf     : Disney evaluation for the light sample, direction sampling, roulette (the fat, divergent code) over
+//              the listed records; the continuing path moves to the next path queue
 //   drain    : once every sample has been started and few paths remain, each runs to its end in one
 //              kernel instead of one launch sequence per remaining path vertex
 //   accumulate: adds the per-sample results to the accumulator in frame order per pixel
 //
-// A slot whose sample is finished writes the sample's value to a staging array and immediately
-// takes the next unstarted sample id (from a 256-id chunk its workgroup holds), so the pool stays
-// full until the work runs out.  Which slot renders which sample does not matter: a sample's value
+// Every stage kernel therefore runs waves whose 64 lanes do the same kind of work on consecutive records: the
+// reference's megakernel interleaves these kinds per thread (pathtracer.cu:405-481 with :267-339 nested in it), and a
+// pool of slots that stay in place mixes them per wave.
+//
+// A finished sample writes its value to a staging array and the lane starts the next unstarted sample (from a
+// 256-id chunk its workgroup holds), so the number of samples in flight stays at the pool size until the
+// work runs out.  Which queue position renders which sample does not matter: a sample's value
 // depends only on (pixel, frame) through its counter-based random stream, and the ordered
 // accumulate pass makes the sum independent of scheduling.  Results are therefore bit-identical to
 // the frame loop of the reference (pathtracer.cu:583-586) whatever the pool size or lane count.
@@ -32,20 +40,20 @@ namespace ptamd {
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kPlanThreads = 1024;      // the single-workgroup planning kernels
+constexpr uint32_t kNone = 0xFFFFFFFFu;
 
-// flags word: state[1:0] ch[3:2] inside[4] surface_scatter[5] sh_inside[6] nee_surface[7] nee_skip[8] v_inside[9] seg[15:10] lobes[19:16]
+// flags word: state[1:0] ch[3:2] inside[4] surface_scatter[5] sh_inside[6] nee_surface[7] nee_skip[8] v_inside[9] seg[15:10] lobes[19:16] bounce[31:20]
 PT_DEV uint32_t pack_flags(const Path& P)
 {
     return (uint32_t)P.state | ((uint32_t)(P.ch & 3) << 2) | ((uint32_t)P.inside << 4) | ((uint32_t)P.surface_scatter << 5) |
            ((uint32_t)P.sh_inside << 6) | ((uint32_t)P.nee_surface << 7) | ((uint32_t)P.nee_skip << 8) | ((uint32_t)P.v_inside << 9) |
-           ((uint32_t)(P.seg & 63) << 10) | ((uint32_t)(P.lobes & 15) << 16);
+           ((uint32_t)(P.seg & 63) << 10) | ((uint32_t)(P.lobes & 15) << 16) | ((uint32_t)P.bounce << 20);
 }
 PT_DEV void unpack_flags(Path& P, uint32_t f)
 {
     P.state = (int)(f & 3u); P.ch = (int)((f >> 2) & 3u); P.inside = (f >> 4) & 1u; P.surface_scatter = (f >> 5) & 1u;
     P.sh_inside = (f >> 6) & 1u; P.nee_surface = (f >> 7) & 1u; P.nee_skip = (f >> 8) & 1u; P.v_inside = (f >> 9) & 1u;
-    P.seg = (int)((f >> 10) & 63u); P.lobes = (int)((f >> 16) & 15u);
+    P.seg = (int)((f >> 10) & 63u); P.lobes = (int)((f >> 16) & 15u); P.bounce = (int)(f >> 20);
 }
 
 struct SampleId { int x, y, frame; uint32_t pixel; uint32_t stage_index; };
@@ -78,24 +86,16 @@ PT_DEV SampleId decode_sample(const WfParams& w, uint32_t s)
     return id;
 }
 
-// ---- slot state in HBM: structure of 16-byte arrays, slot-indexed, so a wave's access is contiguous
-PT_DEV void store_ray(const WfParams& w, uint32_t slot, const Path& P)
+// ---- records in HBM: structures of 16-byte arrays indexed by queue position, so a wave's access is contiguous
+PT_DEV void store_core(float4* c0, float4* c1, float4* c2, uint32_t i, const Path& P, uint32_t sample)
 {
-    bool shadow = P.state == ST_SHADOW;
-    F3 o = shadow ? P.so : P.o, d = shadow ? P.sd : P.d;
-    int live = (P.state == ST_PATH || P.state == ST_SHADOW) ? 1 : 0;
-    w.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.f);
-    w.ray_d[slot] = make_float4(d.x, d.y, d.z, __int_as_float(live));
+    c0[i] = make_float4(P.o.x, P.o.y, P.o.z, P.thr);
+    c1[i] = make_float4(P.d.x, P.d.y, P.d.z, P.pdf);
+    c2[i] = make_float4(P.result, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), __uint_as_float(sample));
 }
-PT_DEV void store_core(const WfParams& w, uint32_t slot, const Path& P, uint32_t sample)
+PT_DEV uint32_t load_core(const float4* c0, const float4* c1, const float4* c2, uint32_t i, const WfParams& w, Path& P, SampleId& id)
 {
-    w.c0[slot] = make_float4(P.o.x, P.o.y, P.o.z, P.thr);
-    w.c1[slot] = make_float4(P.d.x, P.d.y, P.d.z, P.pdf);
-    w.c2[slot] = make_float4(P.result, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), __uint_as_float(sample));
-}
-PT_DEV uint32_t load_core(const WfParams& w, uint32_t slot, Path& P, SampleId& id)
-{
-    float4 a = w.c0[slot], b = w.c1[slot], c = w.c2[slot];
+    float4 a = c0[i], b = c1[i], c = c2[i];
     P.o = f3(a.x, a.y, a.z); P.thr = a.w;
     P.d = f3(b.x, b.y, b.z); P.pdf = b.w;
     P.result = c.x;
@@ -105,29 +105,36 @@ PT_DEV uint32_t load_core(const WfParams& w, uint32_t slot, Path& P, SampleId& i
     rng_seed(P.rng, id.pixel, (uint32_t)id.frame, __float_as_uint(c.z));
     return sample;
 }
-PT_DEV void store_light(const WfParams& w, uint32_t slot, const Path& P)
+PT_DEV void store_path(const WfPathQueue& q, uint32_t i, const Path& P, uint32_t sample) { store_core(q.c0, q.c1, q.c2, i, P, sample); }
+// a record of the path queue; the fields only a light sample sets start out cleared
+PT_DEV uint32_t load_path(const WfPathQueue& q, uint32_t i, const WfParams& w, Path& P, SampleId& id)
 {
-    w.d0[slot] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
-    w.d1[slot] = make_float4(P.env_color.x, P.env_color.y, P.env_color.z, __int_as_float(P.bounce));
+    P.so = P.sd = P.light = P.env_color = f3(0.f, 0.f, 0.f); P.env_pdf = 0.f;
+    return load_core(q.c0, q.c1, q.c2, i, w, P, id);
 }
-PT_DEV void load_light(const WfParams& w, uint32_t slot, Path& P)
-{
-    float4 a = w.d0[slot], b = w.d1[slot];
-    P.light = f3(a.x, a.y, a.z); P.env_pdf = a.w;
-    P.env_color = f3(b.x, b.y, b.z); P.bounce = __float_as_int(b.w);
-}
-PT_DEV void store_vertex(const WfParams& w, uint32_t slot, const Path& P)
+// a whole record of the shadow queue; the record waits for the hit of (so, sd) while state is ST_SHADOW
+PT_DEV void store_shadow(const WfShadowQueue& q, uint32_t i, const Path& P, uint32_t sample)
 {
     const Mat& m = P.vm;
-    w.e0[slot] = make_float4(m.base.x, m.base.y, m.base.z, m.rough);
-    w.e1[slot] = make_float4(m.emis.x, m.emis.y, m.emis.z, m.aniso);
-    w.e2[slot] = make_float4(m.metal, m.subsurf, m.sheen, m.coat);
-    w.e3[slot] = make_float4(m.coat_rough, m.strans, m.ior, m.G);
-    w.e4[slot] = make_float4(P.vn.x, P.vn.y, P.vn.z, m.alpha);
+    q.so[i] = make_float4(P.so.x, P.so.y, P.so.z, 0.f);
+    q.sd[i] = make_float4(P.sd.x, P.sd.y, P.sd.z, __int_as_float(P.state == ST_SHADOW ? 1 : 0));
+    store_core(q.c0, q.c1, q.c2, i, P, sample);
+    q.d0[i] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
+    q.d1[i] = make_float4(P.env_color.x, P.env_color.y, P.env_color.z, 0.f);
+    q.e0[i] = make_float4(m.base.x, m.base.y, m.base.z, m.rough);
+    q.e1[i] = make_float4(m.emis.x, m.emis.y, m.emis.z, m.aniso);
+    q.e2[i] = make_float4(m.metal, m.subsurf, m.sheen, m.coat);
+    q.e3[i] = make_float4(m.coat_rough, m.strans, m.ior, m.G);
+    q.e4[i] = make_float4(P.vn.x, P.vn.y, P.vn.z, m.alpha);
 }
-PT_DEV void load_vertex(const WfParams& w, uint32_t slot, Path& P)
+PT_DEV uint32_t load_shadow(const WfShadowQueue& q, uint32_t i, const WfParams& w, Path& P, SampleId& id)
 {
-    float4 a = w.e0[slot], b = w.e1[slot], c = w.e2[slot], d = w.e3[slot], e = w.e4[slot];
+    float4 so = q.so[i], sd = q.sd[i], l0 = q.d0[i], l1 = q.d1[i];
+    float4 a = q.e0[i], b = q.e1[i], c = q.e2[i], d = q.e3[i], e = q.e4[i];
+    uint32_t sample = load_core(q.c0, q.c1, q.c2, i, w, P, id);
+    P.so = f3(so.x, so.y, so.z); P.sd = f3(sd.x, sd.y, sd.z);
+    P.light = f3(l0.x, l0.y, l0.z); P.env_pdf = l0.w;
+    P.env_color = f3(l1.x, l1.y, l1.z);
     Mat& m = P.vm;
     m.base = f3(a.x, a.y, a.z); m.rough = a.w;
     m.emis = f3(b.x, b.y, b.z); m.aniso = b.w;
@@ -135,33 +142,30 @@ PT_DEV void load_vertex(const WfParams& w, uint32_t slot, Path& P)
     m.coat_rough = d.x; m.strans = d.y; m.ior = d.z; m.G = d.w;
     P.vn = f3(e.x, e.y, e.z); m.alpha = e.w;
     m.sigA = f3(0.f, 0.f, 0.f); m.sigS = f3(0.f, 0.f, 0.f);     // not used after the vertex
+    return sample;
 }
 
 // Sample ids are handed out per workgroup from a chunk of kSampleChunk consecutive ids that the
-// workgroup owns (four 8x8 tiles of one frame when the image is tiled). The chunk cursor lives in
-// global memory between launches; a new chunk costs one atomic on the global counter, so a launch over
-// millions of slots issues a few thousand atomics instead of one per wave (a single counter word
-// serves only about 90 returning atomics per microsecond chip-wide). The chunk belongs to the
-// workgroup, not to a wave, because the bsdf stage runs a slot on whichever wave its queue position
-// falls to: every slot of a workgroup must draw from the same cursor, or ids left in one wave's chunk
-// would be stranded once that wave's own slots have retired.
+// workgroup owns (four 8x8 tiles of one frame when the image is tiled). The stage kernels are launched with a
+// fixed number of persistent workgroups that take 256-record segments of their queue in turn; workgroup b of any
+// stage launch owns chunk b, whose cursor lives in global memory between launches. A new chunk costs one atomic on
+// the global counter, so a launch over millions of records issues a few thousand atomics instead of one per
+// wave (a single counter word serves only about 90 returning atomics per microsecond chip-wide). Ids left in
+// chunks when the global counter has run out are started by wf_flush_leftover_kernel.
 constexpr uint32_t kSampleChunk = 256;
 
 // A finished sample: publish its value (pathtracer.cu:540,580: channel value * 3, clamped below at 0)
-// and start the next unstarted sample in this slot, if any. Must be called by every thread of the
+// and start the next unstarted sample in this lane, if any. Must be called by every thread of the
 // workgroup (it synchronises).
 template <bool COUNT>
-PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_t slot, Path& P, uint32_t& sample, SampleId& id, bool finished, uint32_t& nsamples, bool first_fill)
+PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, Path& P, uint32_t& sample, SampleId& id, bool finished, uint32_t& nsamples)
 {
     __shared__ uint32_t s_need[kBlock / 64];
     __shared__ uint32_t s_plan[3];      // old cursor, ids available at the old cursor, base of the new chunk
     __shared__ uint32_t s_chunk[2];     // cursor and end of the workgroup's chunk
     const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-    uint32_t* cw = w.block_chunk + 2 * (size_t)blockIdx.x;
-    if (threadIdx.x == 0) {
-        s_chunk[0] = first_fill ? 0u : cw[0];
-        s_chunk[1] = first_fill ? 0u : cw[1];
-    }
+    uint32_t* cw = w.wg_chunk + 2 * (size_t)blockIdx.x;
+    if (threadIdx.x == 0) { s_chunk[0] = cw[0]; s_chunk[1] = cw[1]; }
     // loops only while some fresh sample is born finished (its channel draw was exactly 1.0: 3e-8)
     for (;;) {
         if (finished) {
@@ -183,7 +187,7 @@ PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_
                 s_plan[1] = total; s_plan[2] = 0;
                 next += total;
             } else if (next >= w.n_samples) {
-                // every sample id has been handed out (the cursor was parked at n_samples): the slots retire
+                // every sample id has been handed out (the cursor was parked at n_samples): the lanes retire
                 s_plan[1] = 0; s_plan[2] = w.n_samples;
             } else {
                 uint32_t c = atomicAdd(w.counters + WF_CTR_NEXT_SAMPLE, kSampleChunk);
@@ -204,8 +208,8 @@ PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_
                 if (COUNT) nsamples++;
                 finished = P.state == ST_DONE;
             } else {
-                P.state = ST_DONE;      // pool slot retires
-                sample = 0xFFFFFFFFu;
+                P.state = ST_DONE;      // nothing left to start: the lane emits no record
+                sample = kNone;
                 finished = false;
             }
         }
@@ -214,44 +218,52 @@ PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, uint32_
     if (threadIdx.x == 0) { cw[0] = s_chunk[0]; cw[1] = s_chunk[1]; }
 }
 
-// Number of threads of the workgroup for which pred holds; every thread must call it.
-PT_DEV uint32_t block_count(bool pred)
+// Queue positions for the lanes of a workgroup that append to a queue: the lanes for which `want` holds get
+// consecutive positions, in thread order, from one atomic on the queue's tail word. Every thread of the workgroup
+// must call it (it synchronises); the others get kNone. Up to three queues at once share the two barriers.
+struct Appends { bool want[3]; uint32_t* tail[3]; uint32_t pos[3]; };
+template <int N>
+PT_DEV void reserve(Appends& a)
 {
-    __shared__ uint32_t s_c[kBlock / 64];
-    unsigned long long m = __ballot(pred);
-    if ((threadIdx.x & 63u) == 0) s_c[threadIdx.x >> 6] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t total = 0;
+    __shared__ uint32_t s_cnt[3][kBlock / 64];
+    __shared__ uint32_t s_base[3];
+    const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
+    unsigned long long m[3];
 #pragma unroll
-    for (int j = 0; j < kBlock / 64; j++) total += s_c[j];
-    __syncthreads();
-    return total;
-}
-
-// First fill of the pool: like finish_and_regenerate with every slot "finished", except that there is
-// no previous sample to publish.
-template <bool COUNT>
-PT_DEV void first_fill_regenerate(const WfParams& w, const DCamera& cam, uint32_t slot, Path& P, uint32_t& sample, SampleId& id, uint32_t& nsamples)
-{
-    __shared__ uint32_t s_base;
-    // one chunk request for the whole workgroup: kBlock consecutive ids
-    if (threadIdx.x == 0) s_base = atomicAdd(w.counters + WF_CTR_NEXT_SAMPLE, (uint32_t)kBlock);
-    __syncthreads();
-    uint32_t next = s_base + threadIdx.x;
-    bool finished = false;
-    if (next < w.n_samples) {
-        sample = next;
-        id = decode_sample(w, sample);
-        begin_sample(P, cam, id.x, id.y, id.frame);
-        if (COUNT) nsamples++;
-        finished = P.state == ST_DONE;
-    } else {
-        P.state = ST_DONE;
-        sample = 0xFFFFFFFFu;
+    for (int k = 0; k < N; k++) {
+        m[k] = __ballot(a.want[k]);
+        if (lane == 0) s_cnt[k][wid] = (uint32_t)__popcll(m[k]);
     }
     __syncthreads();
-    // born-finished samples (and nothing else) go through the regular path; it also initialises the cursor
-    finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples, true);
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        if (threadIdx.x == (unsigned)(k * 64)) {        // one lane of a different wave per queue: the atomics go out together
+            uint32_t total = 0;
+#pragma unroll
+            for (int j = 0; j < kBlock / 64; j++) total += s_cnt[k][j];
+            s_base[k] = total ? atomicAdd(a.tail[k], total) : 0u;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        uint32_t woff = 0;
+#pragma unroll
+        for (int j = 0; j < kBlock / 64; j++) if (j < wid) woff += s_cnt[k][j];
+        a.pos[k] = a.want[k] ? s_base[k] + woff + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull)) : kNone;
+    }
+    __syncthreads();                    // the counts are reused by the caller's next segment
+}
+
+// The next 256-record segment of a stage's input for this workgroup (every thread must call it).
+PT_DEV uint32_t next_segment(uint32_t* cursor)
+{
+    __shared__ uint32_t s_seg;
+    if (threadIdx.x == 0) s_seg = atomicAdd(cursor, 1u);
+    __syncthreads();
+    const uint32_t seg = s_seg;
+    __syncthreads();
+    return seg;
 }
 
 template <bool COUNT>
@@ -277,35 +289,70 @@ PT_DEV void flush_tally(DCounters* ctr, const Tally& tl, uint32_t nsamples)
 } // namespace
 
 // ---------------------------------------------------------------- generate
+// The first samples of a chunk of frames: ids [0, n_start) as camera rays at the front of the path queue the
+// first iteration reads (passed here as the "next" one).
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera cam, DCounters* ctr)
+__global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera cam, uint32_t n_start, DCounters* ctr)
 {
-    uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    Path P;                                        // n_slots is a multiple of the workgroup size: no tail
-    P.state = ST_DONE; P.result = 0.f; P.ch = 0; P.rng.draws = 0;
-    P.inside = P.surface_scatter = P.sh_inside = P.nee_surface = P.nee_skip = P.v_inside = false;
-    P.seg = 0; P.bounce = 0; P.thr = 1.f; P.pdf = 0.f; P.lobes = 0;
-    P.o = P.d = P.so = P.sd = P.light = P.env_color = f3(0.f, 0.f, 0.f); P.env_pdf = 0.f;
-    uint32_t sample = 0xFFFFFFFFu;
+    const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
+    Path P;
+    P.state = ST_DONE;
     SampleId id = decode_sample(w, 0);
     uint32_t nsamples = 0;
-    first_fill_regenerate<COUNT>(w, cam, slot, P, sample, id, nsamples);
-    store_ray(w, slot, P);
-    store_core(w, slot, P, sample);
-    store_light(w, slot, P);
-    {
-        uint32_t nr = block_count(P.state != ST_DONE);
-        if (threadIdx.x == 0) w.chunk_rays[blockIdx.x] = nr;
+    bool have = s < n_start;
+    if (have) {
+        id = decode_sample(w, s);
+        P.so = P.sd = P.light = P.env_color = f3(0.f, 0.f, 0.f); P.env_pdf = 0.f;
+        P.sh_inside = P.nee_surface = P.nee_skip = P.v_inside = false; P.seg = 0;
+        begin_sample(P, cam, id.x, id.y, id.frame);
+        if (COUNT) nsamples++;
+        if (P.state == ST_DONE) { w.staging[id.stage_index] = 0.f; have = false; }      // born finished: its channel draw was exactly 1.0
     }
+    Appends a;
+    a.want[0] = have; a.tail[0] = w.counters + WF_CTR_TAIL_P;
+    reserve<1>(a);
+    if (have) store_path(w.Pn, a.pos[0], P, s);
+    if (blockIdx.x == 0 && threadIdx.x == 0) w.counters[WF_CTR_NEXT_SAMPLE] = n_start;
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
 
+// ---------------------------------------------------------------- plan
+// Runs before every extend launch (one small workgroup): what the stages of the last iteration appended becomes
+// the current queues, and the per-iteration counters start over.
+__global__ __launch_bounds__(kBlock) void wf_plan_kernel(uint32_t* __restrict__ counters, const uint32_t* __restrict__ wg_chunk, int stage_blocks, uint32_t n_samples)
+{
+    __shared__ uint32_t s_left[kBlock / 64];
+    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    uint32_t lsum = 0;          // sample ids still waiting in the workgroups' chunks
+    for (int b = tid; b < stage_blocks; b += kBlock) {
+        uint32_t cur = wg_chunk[2 * b], end = wg_chunk[2 * b + 1];
+        cur = cur < n_samples ? cur : n_samples; end = end < n_samples ? end : n_samples;
+        lsum += end > cur ? end - cur : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1) lsum += (uint32_t)__shfl_down((int)lsum, o, 64);
+    if (lane == 0) s_left[wid] = lsum;
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t leftover = 0;
+        for (int j = 0; j < kBlock / 64; j++) leftover += s_left[j];
+        const uint32_t nP = counters[WF_CTR_TAIL_P], nS = counters[WF_CTR_TAIL_S];
+        counters[WF_CTR_N_P] = nP; counters[WF_CTR_N_S] = nS;
+        counters[WF_CTR_TAIL_P] = 0; counters[WF_CTR_TAIL_S] = 0; counters[WF_CTR_TAIL_B] = 0;
+        counters[WF_CTR_RAY_NEXT] = 0;
+        counters[WF_CTR_SEG_PATH] = 0; counters[WF_CTR_SEG_SHADOW] = 0; counters[WF_CTR_SEG_BSDF] = 0;
+        counters[WF_CTR_RAY_P_CHUNKS] = (nP + kBlock - 1) / kBlock;
+        counters[WF_CTR_RAY_CHUNKS] = (nP + kBlock - 1) / kBlock + (nS + kBlock - 1) / kBlock;
+        counters[WF_CTR_LEFTOVER] = leftover;
+    }
+}
+
 // ---------------------------------------------------------------- extend
-// Persistent waves over the pool's rays. Traversal lengths vary by more than 10x between rays, so a
+// Persistent waves over the rays of both queues. Traversal lengths vary by more than 10x between rays, so a
 // wave that kept its 64 rays until the last one finished would run mostly empty (measured: about 6
 // of 64 lanes busy). Here a lane whose ray is finished takes the next untraced ray (from a block of
-// 256 slots the wave took with one atomic) as soon as w.refill_lanes lanes are idle, and leaf work is
+// 256 queue positions the wave took with one atomic: path-queue blocks first, then shadow-queue blocks) as soon as
+// w.refill_lanes lanes are idle, and leaf work is
 // postponed until w.leaf_vote lanes wait at a leaf (or nobody can descend), so each pass of the loop
 // does one kind of work for most lanes.
 //   COUNT: walks the 64-byte fp32 binary nodes in the reference's order and tallies box and triangle
@@ -318,9 +365,6 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
 #endif
 #ifndef PT_TAIL_FACTOR
 #define PT_TAIL_FACTOR 2u
-#endif
-#ifndef PT_STAMPS_SHADE
-#define PT_STAMPS_SHADE 0     // diagnostic build: section clocks of the shade kernel
 #endif
 #ifndef PT_STAMPS
 #define PT_STAMPS 0      // diagnostic build: pass statistics of the extend kernel
@@ -345,7 +389,9 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     bool has_ray = false;
     bool more = true;
     uint32_t chunk_next = 0, chunk_end = 0;      // wave-uniform
-    const uint32_t n_chunks = w.counters[WF_CTR_RAY_CHUNKS];
+    bool chunk_shadow = false;                   // wave-uniform: the block in hand belongs to the shadow queue
+    const uint32_t n_chunks = w.counters[WF_CTR_RAY_CHUNKS], n_pchunks = w.counters[WF_CTR_RAY_P_CHUNKS];
+    const uint32_t n_path = w.counters[WF_CTR_N_P], n_shadow = w.counters[WF_CTR_N_S];
     const uint32_t n_small = n_chunks < PT_TAIL_FACTOR * gridDim.x ? n_chunks : PT_TAIL_FACTOR * gridDim.x, n_big = n_chunks - n_small;
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
 #if PT_STAMPS
@@ -373,7 +419,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         return PT_TRAV_EMPTY;
     };
     auto retire = [&]() {      // the ray of this lane is finished: publish its hit
-        w.hit[slot] = make_float4(best.t, __uint_as_float(best.tri), best.u, best.v);
+        ((slot >> 31) ? w.hitS : w.hitP)[slot & 0x7FFFFFFFu] = make_float4(best.t, __uint_as_float(best.tri), best.u, best.v);
         has_ray = false;
 #if PT_STAMPS
         st_h64 += st_age >= 64; st_h128 += st_age >= 128; st_h256 += st_age >= 256; st_h512 += st_age >= 512; st_max = st_age > st_max ? st_age : st_max;
@@ -411,23 +457,20 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         uint32_t idx = 0;
         float4 ro4 = make_float4(0.f, 0.f, 0.f, 0.f), rd4 = ro4;
         if (do_refill) {
-            // rays are handed out in blocks of kRayChunk consecutive slots, taken with one atomic each from the
-            // list of blocks that hold rays (a static deal of list entries to waves was measured slower)
+            // rays are handed out in blocks of kRayChunk consecutive queue positions, taken with one atomic each
+            // (a static deal of blocks to waves was measured slower)
             if (chunk_next >= chunk_end) {
                 uint32_t li = 0;
                 if (lane == 0) li = atomicAdd(w.counters + WF_CTR_RAY_NEXT, 1u);
                 li = (uint32_t)__builtin_amdgcn_readfirstlane((int)li);
                 if (li >= n_big + 4u * n_small) { more = false; chunk_end = chunk_next; }
-                else if (li < n_big) {
-                    uint32_t c = w.chunk_list[li] * (uint32_t)kRayChunk;
-                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                    chunk_next = c; chunk_end = c + kRayChunk;
-                } else {
+                else {
                     // the last blocks go out in quarters, so that no wave ends the launch alone with 256 rays
-                    uint32_t j = li - n_big;
-                    uint32_t c = w.chunk_list[n_big + (j >> 2)] * (uint32_t)kRayChunk + (j & 3u) * (uint32_t)(kRayChunk / 4);
-                    c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
-                    chunk_next = c; chunk_end = c + kRayChunk / 4;
+                    uint32_t blk = li, off = 0, len = kRayChunk;
+                    if (li >= n_big) { const uint32_t j = li - n_big; blk = n_big + (j >> 2); off = (j & 3u) * (uint32_t)(kRayChunk / 4); len = kRayChunk / 4; }
+                    chunk_shadow = blk >= n_pchunks;
+                    chunk_next = (chunk_shadow ? blk - n_pchunks : blk) * (uint32_t)kRayChunk + off;
+                    chunk_end = chunk_next + len;
                 }
             }
             const uint32_t avail = chunk_end - chunk_next;
@@ -435,7 +478,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
             got = idle && rank < avail;
             idx = chunk_next + rank;
             chunk_next += (uint32_t)n_idle < avail ? (uint32_t)n_idle : avail;
-            if (got) { rd4 = w.ray_d[idx]; ro4 = w.ray_o[idx]; }
+            // a path record's ray is its (o, d); a shadow record's the pending segment of its visibility walk
+            if (got) { rd4 = (chunk_shadow ? w.Sc.sd : w.Pc.c1)[idx]; ro4 = (chunk_shadow ? w.Sc.so : w.Pc.c0)[idx]; }
         }
         float4 n0 = ro4, n1 = ro4, n2 = ro4, n3 = ro4;
         if (descending) {
@@ -560,8 +604,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
             if (cur == PT_TRAV_EMPTY) retire();
         }
         // ---- new rays for the lanes that were idle
-        if (got && __float_as_int(rd4.w) != 0) {
-            slot = idx;
+        if (got && (chunk_shadow ? (idx < n_shadow && __float_as_int(rd4.w) != 0) : idx < n_path)) {
+            slot = idx | (chunk_shadow ? 0x80000000u : 0u);
             o = f3(ro4.x, ro4.y, ro4.z); d = f3(rd4.x, rd4.y, rd4.z);
             best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
             sp = 0;
@@ -613,76 +657,104 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     flush_tally<COUNT>(ctr, tl, 0);
 }
 
-// ---------------------------------------------------------------- shade
+// ---------------------------------------------------------------- path
+// One vertex of pathtrace (pathtracer.cu:406-481) for every record of the path queue, up to the point where the
+// sample needs its next ray. Persistent workgroups take 256-record segments in turn.
+#ifndef PT_PATH_WAVES
+#define PT_PATH_WAVES 3
+#endif
 template <bool COUNT>
-#ifndef PT_SHADE_WAVES
-#define PT_SHADE_WAVES 3
-#endif
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE_WAVES))) void wf_shade_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_PATH_WAVES))) void wf_path_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
-    uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
-    if (slot >= (uint32_t)w.n_slots) return;
-    // counters of the bsdf queue's counting sort (below): zeroed here, where a barrier costs nothing yet
-    constexpr int kKinds = 64;
-    __shared__ uint32_t s_kind[kKinds];
-    if (threadIdx.x < kKinds) s_kind[threadIdx.x] = 0u;
-    __syncthreads();
-#if PT_STAMPS_SHADE
-    // diagnostic build: where a wave's time goes (section clocks, memory waits drained at each stamp)
-    unsigned long long sst[8];
-    unsigned long long ssl[4] = {0, 0, 0, 0};
-#define SST(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); sst[i] = __builtin_amdgcn_s_memtime(); } while (0)
-    SST(0);
-#else
-#define SST(i) do { } while (0)
-#endif
-    float4 rd4 = w.ray_d[slot];
-    bool live = __float_as_int(rd4.w) != 0;
+    const uint32_t n_in = w.counters[WF_CTR_N_P];
+    const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
-    Path P;
-    SampleId id;
-    uint32_t sample = 0xFFFFFFFFu;
-    bool finished = false;
-    if (live) {
-        sample = load_core(w, slot, P, id);
-        load_light(w, slot, P);
-        float4 ro4 = w.ray_o[slot];
-        float4 h4 = w.hit[slot];
-        Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
-        F3 rdir = f3(rd4.x, rd4.y, rd4.z);
-        Surf info;
-        SST(1);
-        resolve_hit<COUNT>(S, h, rdir, info, tl.taps, tl.taps_r, P.state == ST_SHADOW);
-        SST(2);
-#if PT_STAMPS_SHADE
-        ssl[0] = (unsigned long long)__popcll(__ballot(true)); ssl[1] = (unsigned long long)__popcll(__ballot(P.state == ST_SHADOW));
-        ssl[2] = (unsigned long long)__popcll(__ballot(h.tri == PT_NO_TRI));
-        sst[3] = sst[2];
-#endif
-        if (P.state == ST_SHADOW) {
-            P.so = f3(ro4.x, ro4.y, ro4.z); P.sd = rdir;
-            on_shadow_hit<COUNT>(S, cam, P, info, tl);
-            SST(3);
-        } else {
+    for (;;) {
+        const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_PATH);
+        if (seg >= n_seg) break;                    // uniform over the workgroup
+        const uint32_t i = seg * kBlock + threadIdx.x;
+        const bool have = i < n_in;
+        Path P;
+        SampleId id = {0, 0, 0, 0u, 0u};
+        uint32_t sample = kNone;
+        P.state = ST_DONE;
+        bool finished = false;
+        if (have) {
+            sample = load_path(w.Pc, i, w, P, id);
+            float4 h4 = w.hitP[i];
+            Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
+            Surf info;
+            resolve_hit<COUNT>(S, h, P.d, info, tl.taps, tl.taps_r, false);
             on_path_hit<COUNT>(S, cam, P, info, tl);
-            if (P.state == ST_SHADOW || P.state == ST_AFTER) store_vertex(w, slot, P);
+            finished = P.state == ST_DONE;
         }
-        finished = P.state == ST_DONE;
+        finish_and_regenerate<COUNT>(w, cam, P, sample, id, finished, nsamples);
+        // where the record goes: a new or passed-through path ray to the next path queue; a vertex with its light
+        // sample to the next shadow queue, and, when there is no visibility walk to wait for (sun/sky mode draws no
+        // light sample, pathtracer.cu:346-380 has none), straight onto this iteration's bsdf list as well
+        const bool alive = have && P.state != ST_DONE;
+        Appends a;
+        a.want[0] = alive && P.state == ST_PATH; a.tail[0] = w.counters + WF_CTR_TAIL_P;
+        a.want[1] = alive && P.state != ST_PATH; a.tail[1] = w.counters + WF_CTR_TAIL_S;
+        a.want[2] = alive && P.state == ST_AFTER; a.tail[2] = w.counters + WF_CTR_TAIL_B;
+        reserve<3>(a);
+        if (a.want[0]) store_path(w.Pn, a.pos[0], P, sample);
+        if (a.want[1]) store_shadow(w.Sn, a.pos[1], P, sample);
+        if (a.want[2]) w.bsdf_list[a.pos[2]] = a.pos[1] | 0x80000000u;
     }
-#if PT_STAMPS_SHADE
-    else { sst[1] = sst[2] = sst[3] = sst[0]; }
-#endif
-    SST(4);
-    // Slots that reached the bsdf stage go into the workgroup's segment of the queue (block b owns entries
-    // [b*256, b*256 + count[b]); no global atomics), ordered by the kind of work the stage will do for them: which
-    // lobes the material carries (the branches of DisneyEval_2, disney.cuh:294-344), surface or medium vertex, and
-    // whether the light sample arrived (its evaluation is skipped otherwise, pathtracer.cu:318). A counting sort in
-    // LDS: the waves of the bsdf stage then run mostly one kind each instead of every branch for a few lanes.
-    bool to_bsdf = live && P.state == ST_AFTER;
-    {
-        // (s_kind was zeroed at the top of the kernel, a barrier ago)
-        const int lane = (int)(threadIdx.x & 63u);
+    flush_tally<COUNT>(ctr, tl, nsamples);
+}
+
+// ---------------------------------------------------------------- shadow
+// One segment of visibility (pathtracer.cu:279-295) for every record of the shadow queue. The segment looks at
+// alpha, metallic, transmission, ior and the medium of the surface it hit, and draws one number: it needs the
+// walk's part of the record only (64 of 192 bytes) and few registers, so many waves fit a SIMD and hide the
+// dependent loads (hit -> triangle -> material -> texture -> texels). A finished walk stays where it is and its
+// position goes onto the bsdf list, ordered within the workgroup by the kind of work the bsdf stage will do
+// for it; a walk that goes on (it passed an alpha cut-out or an index-matched surface) moves to the next shadow queue.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_shadow_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+{
+    constexpr int kKinds = 64;
+    __shared__ uint32_t s_kind[kKinds];
+    __shared__ uint32_t s_list_base;
+    const uint32_t n_in = w.counters[WF_CTR_N_S];
+    const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
+    const int lane = (int)(threadIdx.x & 63u);
+    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    for (;;) {
+        if (threadIdx.x < kKinds) s_kind[threadIdx.x] = 0u;
+        const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_SHADOW);      // (its barriers also publish the cleared counts)
+        if (seg >= n_seg) break;
+        const uint32_t i = seg * kBlock + threadIdx.x;
+        float4 sd4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < n_in) sd4 = w.Sc.sd[i];
+        // a record without a pending ray was handed to the bsdf stage when it was written (see wf_path_kernel)
+        const bool have = i < n_in && __float_as_int(sd4.w) != 0;
+        Path P;
+        P.state = ST_DONE; P.lobes = 0; P.nee_surface = false; P.nee_skip = false;
+        P.light = f3(0.f, 0.f, 0.f);
+        float4 c2 = sd4;
+        if (have) {
+            float4 so4 = w.Sc.so[i], h4 = w.hitS[i], l0 = w.Sc.d0[i];
+            c2 = w.Sc.c2[i];
+            unpack_flags(P, __float_as_uint(c2.y));
+            const SampleId id = decode_sample(w, __float_as_uint(c2.w));
+            rng_seed(P.rng, id.pixel, (uint32_t)id.frame, __float_as_uint(c2.z));
+            P.so = f3(so4.x, so4.y, so4.z); P.sd = f3(sd4.x, sd4.y, sd4.z);
+            P.light = f3(l0.x, l0.y, l0.z); P.env_pdf = l0.w;
+            Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
+            Surf info;
+            resolve_hit<COUNT>(S, h, P.sd, info, tl.taps, tl.taps_r, true);
+            on_shadow_hit<COUNT>(S, cam, P, info, tl);
+        }
+        const bool to_bsdf = have && P.state == ST_AFTER;
+        const bool goes_on = have && P.state == ST_SHADOW;
+        // Order of this workgroup's entries of the bsdf list: by which lobes the material carries (the branches of
+        // DisneyEval_2, disney.cuh:294-344), surface or medium vertex, and whether the light sample arrived (its
+        // evaluation is skipped otherwise, pathtracer.cu:318). A counting sort in LDS: the waves of the bsdf stage then
+        // run mostly one kind each instead of every branch for a few lanes.
         uint32_t kind = 0, rank = 0;
         if (to_bsdf) {
             const bool lit = !P.nee_skip && !(dot(P.light, P.light) <= 0.05f);
@@ -702,7 +774,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE
             todo &= ~same;
         }
         __syncthreads();
-        // exclusive prefix over the kinds, computed by every wave for itself (lane l holds kind l): no second barrier
+        // exclusive prefix over the kinds, computed by every wave for itself (lane l holds kind l)
         const uint32_t held = s_kind[lane];
         uint32_t incl = held;
 #pragma unroll
@@ -711,168 +783,129 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADE
             if (lane >= dlt) incl += t;
         }
         const uint32_t first = (uint32_t)__shfl((int)(incl - held), (int)kind, 64);
-        if (threadIdx.x == 63) w.bsdf_count[blockIdx.x] = incl;
-        if (to_bsdf) w.bsdf_queue[(size_t)blockIdx.x * kBlock + first + rank] = slot;
-    }
-    SST(5);
-#if PT_STAMPS_SHADE
-    ssl[3] = (unsigned long long)__popcll(__ballot(finished));
-#endif
-    finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples, false);
-    SST(6);
-    if (live) {
-        if (P.state == ST_AFTER) {
-            // the bsdf stage reads the shadow direction from the ray arrays; mark the slot as having no ray to trace
-            w.ray_d[slot] = make_float4(P.sd.x, P.sd.y, P.sd.z, __int_as_float(0));
-        } else {
-            store_ray(w, slot, P);
+        const uint32_t listed = (uint32_t)__shfl((int)incl, 63, 64);
+        if (threadIdx.x == 0) s_list_base = listed ? atomicAdd(w.counters + WF_CTR_TAIL_B, listed) : 0u;
+        Appends a;
+        a.want[0] = goes_on; a.tail[0] = w.counters + WF_CTR_TAIL_S;
+        reserve<1>(a);                              // (its barriers also publish s_list_base and protect s_kind)
+        if (to_bsdf) {
+            // the walk's result stays in the record: transmittance, state and the draws it consumed
+            w.Sc.d0[i] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
+            w.Sc.c2[i] = make_float4(c2.x, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), c2.w);
+            w.bsdf_list[s_list_base + first + rank] = i;
         }
-        store_core(w, slot, P, sample);
-        store_light(w, slot, P);
+        if (goes_on) {
+            const uint32_t j = a.pos[0];
+            w.Sn.so[j] = make_float4(P.so.x, P.so.y, P.so.z, 0.f);
+            w.Sn.sd[j] = sd4;
+            w.Sn.c0[j] = w.Sc.c0[i]; w.Sn.c1[j] = w.Sc.c1[i];
+            w.Sn.c2[j] = make_float4(c2.x, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), c2.w);
+            w.Sn.d0[j] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
+            w.Sn.d1[j] = w.Sc.d1[i];
+            w.Sn.e0[j] = w.Sc.e0[i]; w.Sn.e1[j] = w.Sc.e1[i]; w.Sn.e2[j] = w.Sc.e2[i]; w.Sn.e3[j] = w.Sc.e3[i]; w.Sn.e4[j] = w.Sc.e4[i];
+        }
     }
-    bool alive = live && (P.state != ST_DONE);
-    {
-        // rays this block hands to the next extend launch (slots on their way to the bsdf stage add theirs there)
-        uint32_t nr = block_count(alive && P.state != ST_AFTER);
-        if (threadIdx.x == 0) w.chunk_rays[blockIdx.x] = nr;
-    }
-    if (__any(alive) && (threadIdx.x & 63u) == 0) w.counters[WF_CTR_LIVE] = 1u;     // a flag, not a count: plain store
-#if PT_STAMPS_SHADE
-    SST(7);
-    if ((threadIdx.x & 63u) == 0) {
-        // words: 0 waves, 1 loads, 2 resolve_hit, 3 shadow branch, 4 path branch (+ vertex store), 5 queue sort, 6 regenerate, 7 stores;
-        // 8 live lanes, 9 shadow lanes, 10 miss lanes, 11 finished lanes
-        unsigned long long* dbg = reinterpret_cast<unsigned long long*>(w.counters + WF_CTR_WORDS);
-        atomicAdd(dbg + 0, 1ull); atomicAdd(dbg + 1, sst[1] - sst[0]); atomicAdd(dbg + 2, sst[2] - sst[1]); atomicAdd(dbg + 3, sst[3] - sst[2]);
-        atomicAdd(dbg + 4, sst[4] - sst[3]); atomicAdd(dbg + 5, sst[5] - sst[4]); atomicAdd(dbg + 6, sst[6] - sst[5]); atomicAdd(dbg + 7, sst[7] - sst[6]);
-        atomicAdd(dbg + 8, ssl[0]); atomicAdd(dbg + 9, ssl[1]); atomicAdd(dbg + 10, ssl[2]); atomicAdd(dbg + 11, ssl[3]);
-    }
-#endif
-    flush_tally<COUNT>(ctr, tl, nsamples);
+    flush_tally<COUNT>(ctr, tl, 0);
 }
 
 // ---------------------------------------------------------------- bsdf
-template <bool COUNT>
+// Everything after the light sample of a vertex (pathtracer.cu:318-338, :449-451 or :471-480, :484-490) for the
+// records on the bsdf list.
 #ifndef PT_BSDF_WAVES
 #define PT_BSDF_WAVES 4
 #endif
+template <bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_BSDF_WAVES))) void wf_bsdf_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
-    uint32_t count = w.bsdf_count[blockIdx.x];
-    if (count == 0) return;                              // uniform over the workgroup
-    bool active = threadIdx.x < count;
-    uint32_t q = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t n_in = w.counters[WF_CTR_TAIL_B];
+    const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
+    for (;;) {
+        const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_BSDF);
+        if (seg >= n_seg) break;
+        const uint32_t k = seg * kBlock + threadIdx.x;
+        const bool have = k < n_in;
+        Path P;
+        SampleId id = {0, 0, 0, 0u, 0u};
+        uint32_t sample = kNone;
+        P.state = ST_DONE;
+        bool finished = false;
+        if (have) {
+            const uint32_t e = w.bsdf_list[k];
+            if (e >> 31) sample = load_shadow(w.Sn, e & 0x7FFFFFFFu, w, P, id);
+            else sample = load_shadow(w.Sc, e, w, P, id);
+            after_light<COUNT>(S, cam, P, tl);
+            finished = P.state == ST_DONE;
+        }
+        finish_and_regenerate<COUNT>(w, cam, P, sample, id, finished, nsamples);
+        Appends a;
+        a.want[0] = have && P.state == ST_PATH; a.tail[0] = w.counters + WF_CTR_TAIL_P;
+        reserve<1>(a);
+        if (a.want[0]) store_path(w.Pn, a.pos[0], P, sample);
+    }
+    flush_tally<COUNT>(ctr, tl, nsamples);
+}
+
+// ---------------------------------------------------------------- leftover sample ids
+// Once the global hand-out has run dry, the ids that workgroups still hold in their chunks would wait for those
+// workgroups to finish samples of their own, which the thinning queues give them ever more rarely. This kernel
+// (workgroup b empties chunk b) starts them all at once, as camera rays at the tail of the path queue the next
+// iteration reads. From then on no workgroup holds an id, and a lane whose sample ends emits nothing.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_flush_leftover_kernel(WfParams w, DCamera cam, DCounters* ctr)
+{
+    uint32_t* cw = w.wg_chunk + 2 * (size_t)blockIdx.x;
+    const uint32_t cur = cw[0], end = cw[1] < w.n_samples ? cw[1] : w.n_samples;
+    if (cur >= end) return;                         // uniform over the workgroup
+    __syncthreads();                                // every thread has read the chunk before it is emptied
+    if (threadIdx.x == 0) { cw[0] = w.n_samples; cw[1] = w.n_samples; }
+    const uint32_t s = cur + threadIdx.x;           // a chunk holds at most kSampleChunk = kBlock ids
     Path P;
-    SampleId id;
-    uint32_t sample = 0xFFFFFFFFu;
-    uint32_t slot = 0;
-    bool finished = false;
-    if (active) {
-        slot = w.bsdf_queue[q];
-        sample = load_core(w, slot, P, id);
-        load_light(w, slot, P);
-        load_vertex(w, slot, P);
-        float4 sd4 = w.ray_d[slot];
-        P.sd = f3(sd4.x, sd4.y, sd4.z);
-        after_light<COUNT>(S, cam, P, tl);
-        finished = P.state == ST_DONE;
+    P.state = ST_DONE;
+    uint32_t nsamples = 0;
+    bool have = s < end;
+    if (have) {
+        const SampleId id = decode_sample(w, s);
+        P.so = P.sd = P.light = P.env_color = f3(0.f, 0.f, 0.f); P.env_pdf = 0.f;
+        P.sh_inside = P.nee_surface = P.nee_skip = P.v_inside = false; P.seg = 0;
+        begin_sample(P, cam, id.x, id.y, id.frame);
+        if (COUNT) nsamples++;
+        if (P.state == ST_DONE) { w.staging[id.stage_index] = 0.f; have = false; }
     }
-    finish_and_regenerate<COUNT>(w, cam, slot, P, sample, id, finished, nsamples, false);
-    if (active) {
-        store_ray(w, slot, P);
-        store_core(w, slot, P, sample);
-        store_light(w, slot, P);
-    }
-    {
-        uint32_t nr = block_count(active && P.state != ST_DONE);
-        if (threadIdx.x == 0) w.chunk_rays[blockIdx.x] += nr;      // the shade launch wrote this block's count
-    }
+    Appends a;
+    a.want[0] = have; a.tail[0] = w.counters + WF_CTR_TAIL_P;
+    reserve<1>(a);
+    if (have) store_path(w.Pn, a.pos[0], P, s);
+    Tally tl = {0, 0, 0, 0, 0, 0, 0};
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
 
 // ---------------------------------------------------------------- drain
-// End of a render: every sample id has been handed out by the global counter and few slots still carry a
-// path. Another hundred stage launches for the longest paths would cost their launch latencies in
-// sequence; instead the remaining paths are gathered into a dense list and each runs its sample to the
-// end in one kernel (the same state machine, one path per lane, reference-order traversal with the LDS
-// stack). Sample ids a workgroup still holds in its chunk are started by the lanes whose slots belong
-// to that workgroup as they become free.
-
-// one workgroup: exclusive prefix of the ray counts of the listed slot blocks
-__global__ __launch_bounds__(kPlanThreads) void wf_drain_plan_kernel(uint32_t* __restrict__ counters, const uint32_t* __restrict__ chunk_rays,
-                                                                     const uint32_t* __restrict__ chunk_list, uint32_t* __restrict__ chunk_base)
-{
-    __shared__ uint32_t s_wave[kPlanThreads / 64];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int n = (int)counters[WF_CTR_RAY_CHUNKS];
-    uint32_t base = 0;
-    for (int tile = 0; tile < n; tile += kPlanThreads) {
-        int i = tile + tid;
-        uint32_t mine = i < n ? chunk_rays[chunk_list[i]] : 0u;
-        uint32_t incl = mine;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            uint32_t t = (uint32_t)__shfl_up((int)incl, dlt, 64);
-            if (lane >= dlt) incl += t;
-        }
-        if (lane == 63) s_wave[wid] = incl;
-        __syncthreads();
-        uint32_t woff = 0, total = 0;
-#pragma unroll
-        for (int j = 0; j < kPlanThreads / 64; j++) { uint32_t c = s_wave[j]; if (j < wid) woff += c; total += c; }
-        if (i < n) chunk_base[i] = base + woff + incl - mine;
-        base += total;
-        __syncthreads();
-    }
-    if (tid == 0) counters[WF_CTR_RAYS] = base;
-}
-
-// workgroup i: the slots of listed block i that carry a path, written densely at that block's base
-__global__ __launch_bounds__(kBlock) void wf_drain_gather_kernel(WfParams w, const uint32_t* __restrict__ chunk_base, uint32_t* __restrict__ drain_list)
-{
-    if (blockIdx.x >= w.counters[WF_CTR_RAY_CHUNKS]) return;
-    __shared__ uint32_t s_c[kBlock / 64];
-    uint32_t slot = w.chunk_list[blockIdx.x] * (uint32_t)kBlock + threadIdx.x;
-    bool live = __float_as_int(w.ray_d[slot].w) != 0;
-    unsigned long long m = __ballot(live);
-    const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-    if (lane == 0) s_c[wid] = (uint32_t)__popcll(m);
-    __syncthreads();
-    uint32_t woff = 0;
-#pragma unroll
-    for (int j = 0; j < kBlock / 64; j++) if (j < wid) woff += s_c[j];
-    if (live) drain_list[chunk_base[blockIdx.x] + woff + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = slot;
-}
-
+// End of a render: every sample id has been started and few records are left. Another hundred stage launches
+// for the longest paths would cost their launch latencies in sequence; instead each remaining record runs its
+// sample to the end in one kernel (the same state machine, one path per lane, traversal with the LDS stack).
+// Lane q takes record q of the path queue, or record q - n_path of the shadow queue.
 template <bool COUNT, bool WIDE>
-__global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, DCamera cam, const uint32_t* __restrict__ drain_list, DCounters* ctr)
+__global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
-    const uint32_t n_paths = w.counters[WF_CTR_RAYS];
+    const uint32_t n_path = w.counters[WF_CTR_N_P], n_paths = n_path + w.counters[WF_CTR_N_S];
     if (blockIdx.x * (uint32_t)kBlock >= n_paths) return;
     const uint32_t q = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     bool have = q < n_paths;             // lanes past the end stay for the wave-wide tally
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
-    uint32_t nsamples = 0;
     Path P;
-    SampleId id;
+    SampleId id = {0, 0, 0, 0u, 0u};
     P.state = ST_DONE;
-    uint32_t slot = 0;
     if (have) {
-        slot = drain_list[q];
-        float4 rd4 = w.ray_d[slot];
-        load_core(w, slot, P, id);
-        load_light(w, slot, P);
-        float4 ro4 = w.ray_o[slot];
-        if (P.state == ST_SHADOW) {
-            load_vertex(w, slot, P);
-            P.so = f3(ro4.x, ro4.y, ro4.z); P.sd = f3(rd4.x, rd4.y, rd4.z);
+        if (q < n_path) load_path(w.Pc, q, w, P, id);
+        else {
+            load_shadow(w.Sc, q - n_path, w, P, id);
+            // a record without a pending ray already went through the bsdf stage: its sample lives on elsewhere
+            if (__float_as_int(w.Sc.sd[q - n_path].w) == 0) have = false;
         }
     }
-    uint32_t* cw = w.block_chunk + 2 * (size_t)(slot / kBlock);
-    const uint32_t id_end = have ? (cw[1] < w.n_samples ? cw[1] : w.n_samples) : 0u;
-    while (have) {
+    if (have) {
         while (P.state != ST_DONE) {
             if (P.state == ST_AFTER) { after_light<COUNT>(S, cam, P, tl); continue; }
             bool shadow = P.state == ST_SHADOW;
@@ -889,24 +922,8 @@ __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, 
         }
         float v = P.result * 3.f;
         w.staging[id.stage_index] = v > 0.f ? v : 0.f;
-        // a sample id the slot's workgroup still holds?
-        have = false;
-        if (cw[0] < id_end) {
-            uint32_t next = atomicAdd(cw, 1u);
-            if (next < id_end) {
-                id = decode_sample(w, next);
-                begin_sample(P, cam, id.x, id.y, id.frame);
-                if (COUNT) nsamples++;
-                have = true;
-            }
-        }
     }
-    if (q < n_paths) {
-        w.ray_d[slot] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
-        P.state = ST_DONE;
-        store_core(w, slot, P, 0xFFFFFFFFu);
-    }
-    flush_tally<COUNT>(ctr, tl, nsamples);
+    flush_tally<COUNT>(ctr, tl, 0);
 }
 
 // ---------------------------------------------------------------- accumulate
@@ -933,69 +950,18 @@ __global__ __launch_bounds__(kBlock) void wf_accumulate_kernel(WfParams w, DCame
 }
 
 // ---------------------------------------------------------------- closest-hit batch through the production traversal
-// Runs before every extend launch (one workgroup): compacts the indices of the slot blocks that hold rays
-// into chunk_list, publishes their number, and resets the per-iteration counters.
-__global__ __launch_bounds__(kPlanThreads) void wf_plan_extend_kernel(uint32_t* __restrict__ counters, const uint32_t* __restrict__ chunk_rays,
-                                                                      uint32_t* __restrict__ chunk_list, int n_chunks,
-                                                                      const uint32_t* __restrict__ block_chunk, uint32_t n_samples)
-{
-    __shared__ uint32_t s_wave[kPlanThreads / 64];
-    __shared__ uint32_t s_rays[kPlanThreads / 64];
-    __shared__ uint32_t s_left[kPlanThreads / 64];
-    const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    uint32_t base = 0, rays = 0, leftover = 0;
-    for (int tile = 0; tile < n_chunks; tile += kPlanThreads * 4) {
-        int i0 = tile + tid * 4;
-        uint32_t r[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) r[k] = (i0 + k < n_chunks) ? chunk_rays[i0 + k] : 0u;
-        uint32_t mine = (r[0] != 0) + (r[1] != 0) + (r[2] != 0) + (r[3] != 0);
-        uint32_t rsum = r[0] + r[1] + r[2] + r[3];
-        uint32_t lsum = 0;          // sample ids still waiting in these blocks' chunks
-        if (block_chunk) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) if (i0 + k < n_chunks) {
-                uint32_t cur = block_chunk[2 * (i0 + k)], end = block_chunk[2 * (i0 + k) + 1];
-                cur = cur < n_samples ? cur : n_samples; end = end < n_samples ? end : n_samples;
-                lsum += end > cur ? end - cur : 0u;
-            }
-        }
-        uint32_t incl = mine;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            uint32_t t = (uint32_t)__shfl_up((int)incl, dlt, 64);
-            uint32_t tr = (uint32_t)__shfl_xor((int)rsum, dlt, 64);
-            uint32_t tl = (uint32_t)__shfl_xor((int)lsum, dlt, 64);
-            if (lane >= dlt) incl += t;
-            rsum += tr; lsum += tl;
-        }
-        if (lane == 63) s_wave[wid] = incl;
-        if (lane == 0) { s_rays[wid] = rsum; s_left[wid] = lsum; }
-        __syncthreads();
-        uint32_t woff = 0, total = 0;
-#pragma unroll
-        for (int j = 0; j < kPlanThreads / 64; j++) { uint32_t c = s_wave[j]; if (j < wid) woff += c; total += c; rays += s_rays[j]; leftover += s_left[j]; }
-        uint32_t pos = base + woff + incl - mine;
-#pragma unroll
-        for (int k = 0; k < 4; k++) if (r[k] != 0) chunk_list[pos++] = (uint32_t)(i0 + k);
-        base += total;
-        __syncthreads();
-    }
-    if (tid == 0) {
-        counters[WF_CTR_LIVE] = 0;
-        counters[WF_CTR_RAY_NEXT] = 0;
-        counters[WF_CTR_RAY_CHUNKS] = base;
-        counters[WF_CTR_RAYS] = rays;
-        counters[WF_CTR_LEFTOVER] = leftover;
-    }
-}
-
+// The batch is laid out as a shadow queue of n records (origins, directions with the pending flag set) and an
+// empty path queue, which is all the extend kernel looks at.
 __global__ __launch_bounds__(kBlock) void wf_pack_rays_kernel(const pt_ray* __restrict__ rays, int n, float4* __restrict__ ray_o, float4* __restrict__ ray_d,
-                                                              uint32_t* __restrict__ chunk_rays)
+                                                              uint32_t* __restrict__ counters)
 {
     int i = blockIdx.x * kBlock + threadIdx.x;      // the grid covers n rounded up to whole blocks
-    if (threadIdx.x == 0) chunk_rays[blockIdx.x] = (uint32_t)((n - (int)(blockIdx.x * kBlock)) < kBlock ? (n - (int)(blockIdx.x * kBlock)) : kBlock);
-    if (i >= n) { ray_d[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(0)); return; }
+    if (i == 0) {
+        counters[WF_CTR_N_P] = 0; counters[WF_CTR_N_S] = (uint32_t)n;
+        counters[WF_CTR_RAY_NEXT] = 0;
+        counters[WF_CTR_RAY_P_CHUNKS] = 0; counters[WF_CTR_RAY_CHUNKS] = (uint32_t)((n + kBlock - 1) / kBlock);
+    }
+    if (i >= n) return;
     const float4* r = reinterpret_cast<const float4*>(rays + i);
     float4 o = r[0], d = r[1];
     ray_o[i] = make_float4(o.x, o.y, o.z, 0.f);
@@ -1009,25 +975,24 @@ __global__ __launch_bounds__(kBlock) void wf_unpack_hits_kernel(const float4* __
     pt_hit o; o.t = h.x; o.tri = __float_as_uint(h.y);
     out[i] = o;
 }
+// w: Sc.so, Sc.sd and hitS with room for n rounded up to whole blocks, counters, and the extend tuning
 void launch_wf_trace(const WfParams& w, const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, hipStream_t s)
 {
     dim3 grid((n + kBlock - 1) / kBlock), block(kBlock);
-    hipLaunchKernelGGL(wf_pack_rays_kernel, grid, block, 0, s, rays_dev, n, w.ray_o, w.ray_d, w.chunk_rays);
-    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, (int)grid.x, (const uint32_t*)nullptr, 0u);
+    hipLaunchKernelGGL(wf_pack_rays_kernel, grid, block, 0, s, rays_dev, n, w.Sc.so, w.Sc.sd, w.counters);
     int ext_blocks = (int)grid.x < w.extend_blocks ? (int)grid.x : w.extend_blocks;
     if (S.wide) hipLaunchKernelGGL((wf_extend_kernel<false, true>), dim3(ext_blocks), block, 0, s, w, S, (DCounters*)nullptr);
     else hipLaunchKernelGGL((wf_extend_kernel<false, false>), dim3(ext_blocks), block, 0, s, w, S, (DCounters*)nullptr);
-    hipLaunchKernelGGL(wf_unpack_hits_kernel, grid, block, 0, s, w.hit, n, hits_dev);
+    hipLaunchKernelGGL(wf_unpack_hits_kernel, grid, block, 0, s, w.hitS, n, hits_dev);
 }
 
 // ---------------------------------------------------------------- closest-hit batch without allocations
-// The batch above borrows a slot pool that the library allocates on demand. Callers that must not allocate
+// The batch above borrows queue arrays that the library allocates on demand. Callers that must not allocate
 // (code under graph capture, serving loops) get the same kernels over a fixed block of device memory that
-// is part of the library image: ray origins, ray directions and hits of up to kStaticMaxRays rays, the two
-// per-block word arrays of the planning pass, and the counter words.
-constexpr size_t kStaticBlocks = (size_t)kStaticMaxRays / kBlock;
+// is part of the library image: ray origins, ray directions and hits of up to kStaticMaxRays rays, and the
+// counter words.
 constexpr size_t kStaticCounterBytes = WF_CTR_WORDS * sizeof(uint32_t) + 16 * sizeof(unsigned long long);
-constexpr size_t kStaticBytes = 3 * (size_t)kStaticMaxRays * sizeof(float4) + 2 * kStaticBlocks * sizeof(uint32_t) + kStaticCounterBytes;
+constexpr size_t kStaticBytes = 3 * (size_t)kStaticMaxRays * sizeof(float4) + kStaticCounterBytes;
 static __device__ __align__(256) unsigned char scratch[kStaticBytes];
 
 // Every GPU holds its own copy of the block at its own address; the address is looked up once per device,
@@ -1055,19 +1020,16 @@ hipError_t wf_static_scratch(int device, void** ptr_out)
 
 // n <= kStaticMaxRays rays through the production traversal kernel, every intermediate in the block at
 // `base` (what wf_static_scratch returned for the current device). The block keeps the previous call's
-// contents: the pack kernel rewrites the ray arrays and ray counts of every block the launch covers, the
-// planning pass rewrites the block list and the counter words it hands to the traversal kernel, and the
-// counter words are cleared first, so nothing of an earlier call is read.
+// contents: the pack kernel rewrites the ray arrays of every position the launch covers and the counter words
+// it hands to the traversal kernel, and the counter words are cleared first, so nothing of an earlier call is read.
 hipError_t launch_wf_trace_static(void* base, const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, int refill_lanes, int leaf_vote,
                                   int extend_blocks, hipStream_t s)
 {
     if (!base || n <= 0 || n > kStaticMaxRays) return hipErrorInvalidValue;
     WfParams w{};
     float4* f = static_cast<float4*>(base);
-    w.ray_o = f; w.ray_d = f + kStaticMaxRays; w.hit = f + 2 * (size_t)kStaticMaxRays;
-    w.chunk_rays = reinterpret_cast<uint32_t*>(f + 3 * (size_t)kStaticMaxRays);
-    w.chunk_list = w.chunk_rays + kStaticBlocks;
-    w.counters = w.chunk_list + kStaticBlocks;
+    w.Sc.so = f; w.Sc.sd = f + kStaticMaxRays; w.hitS = f + 2 * (size_t)kStaticMaxRays;
+    w.counters = reinterpret_cast<uint32_t*>(f + 3 * (size_t)kStaticMaxRays);
     w.n_slots = (n + kBlock - 1) / kBlock * kBlock;
     w.refill_lanes = refill_lanes; w.leaf_vote = leaf_vote; w.extend_blocks = extend_blocks;
     hipError_t e = hipMemsetAsync(w.counters, 0, kStaticCounterBytes, s);
@@ -1077,19 +1039,22 @@ hipError_t launch_wf_trace_static(void* base, const DScene& S, const pt_ray* ray
 }
 
 // ---------------------------------------------------------------- launchers
+// w.Pn: the path queue the first iteration will read
 void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, hipStream_t s)
 {
-    dim3 grid((w.n_slots + kBlock - 1) / kBlock), block(kBlock);
-    if (ctr) hipLaunchKernelGGL(wf_generate_kernel<true>, grid, block, 0, s, w, cam, ctr);
-    else hipLaunchKernelGGL(wf_generate_kernel<false>, grid, block, 0, s, w, cam, ctr);
+    const uint32_t n_start = (uint32_t)w.n_slots < w.n_samples ? (uint32_t)w.n_slots : w.n_samples;
+    dim3 grid((n_start + kBlock - 1) / kBlock), block(kBlock);
+    if (ctr) hipLaunchKernelGGL(wf_generate_kernel<true>, grid, block, 0, s, w, cam, n_start, ctr);
+    else hipLaunchKernelGGL(wf_generate_kernel<false>, grid, block, 0, s, w, cam, n_start, ctr);
 }
 
+// One iteration: the queues the last iteration appended to (w.Pc, w.Sc) are traced and consumed, w.Pn and w.Sn filled.
 void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t ext0, hipEvent_t ext1)
 {
-    dim3 grid((w.n_slots + kBlock - 1) / kBlock), block(kBlock);
-    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, w.n_slots / kBlock, (const uint32_t*)w.block_chunk, w.n_samples);
+    dim3 block(kBlock), stage(w.stage_blocks);
+    hipLaunchKernelGGL(wf_plan_kernel, dim3(1), block, 0, s, w.counters, (const uint32_t*)w.wg_chunk, w.stage_blocks, w.n_samples);
     if (ext0) (void)hipEventRecord(ext0, s);
-    // persistent waves: enough workgroups to fill every CU, each pulls rays until the pool is drained
+    // persistent waves: enough workgroups to fill every CU, each pulls rays until both queues are drained
     int ext_blocks = (w.n_slots + kBlock - 1) / kBlock;
     if (ext_blocks > w.extend_blocks) ext_blocks = w.extend_blocks;
     if (ctr && w.count_wide && S.wide) hipLaunchKernelGGL((wf_extend_kernel<true, true>), dim3(ext_blocks), block, 0, s, w, S, ctr);
@@ -1098,69 +1063,33 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
     else hipLaunchKernelGGL((wf_extend_kernel<false, false>), dim3(ext_blocks), block, 0, s, w, S, ctr);
     if (ext1) (void)hipEventRecord(ext1, s);
     if (ctr) {
-        hipLaunchKernelGGL(wf_shade_kernel<true>, grid, block, 0, s, w, S, cam, ctr);
-        hipLaunchKernelGGL(wf_bsdf_kernel<true>, grid, block, 0, s, w, S, cam, ctr);
+        hipLaunchKernelGGL(wf_shadow_kernel<true>, stage, block, 0, s, w, S, cam, ctr);
+        hipLaunchKernelGGL(wf_path_kernel<true>, stage, block, 0, s, w, S, cam, ctr);
+        hipLaunchKernelGGL(wf_bsdf_kernel<true>, stage, block, 0, s, w, S, cam, ctr);
     } else {
-        hipLaunchKernelGGL(wf_shade_kernel<false>, grid, block, 0, s, w, S, cam, ctr);
-        hipLaunchKernelGGL(wf_bsdf_kernel<false>, grid, block, 0, s, w, S, cam, ctr);
+        hipLaunchKernelGGL(wf_shadow_kernel<false>, stage, block, 0, s, w, S, cam, ctr);
+        hipLaunchKernelGGL(wf_path_kernel<false>, stage, block, 0, s, w, S, cam, ctr);
+        hipLaunchKernelGGL(wf_bsdf_kernel<false>, stage, block, 0, s, w, S, cam, ctr);
     }
 }
 
-// ---------------------------------------------------------------- repack
-// While a render runs down, the slots that still carry a path are scattered over the pool and every stage
-// pays for the dead ones around them. Once no workgroup holds sample ids any more, the live slots can be
-// moved, in order, to the front of a second, smaller pool; the stages then run on dense blocks again.
-__global__ __launch_bounds__(kBlock) void wf_repack_kernel(WfParams src, WfParams dst, const uint32_t* __restrict__ live_list)
+// w.Pn: the path queue the next iteration will read (its tail word is still open)
+void launch_wf_flush_leftover(const WfParams& w, const DCamera& cam, DCounters* ctr, hipStream_t s)
 {
-    const uint32_t n_live = src.counters[WF_CTR_RAYS];
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;       // destination slot; the grid covers dst.n_slots
-    if (i < n_live) {
-        const uint32_t s = live_list[i];
-        dst.ray_o[i] = src.ray_o[s]; dst.ray_d[i] = src.ray_d[s];
-        dst.c0[i] = src.c0[s]; dst.c1[i] = src.c1[s]; dst.c2[i] = src.c2[s];
-        dst.d0[i] = src.d0[s]; dst.d1[i] = src.d1[s];
-        dst.e0[i] = src.e0[s]; dst.e1[i] = src.e1[s]; dst.e2[i] = src.e2[s]; dst.e3[i] = src.e3[s]; dst.e4[i] = src.e4[s];
-    } else {
-        // an empty slot: no ray, state "done", no sample
-        dst.ray_d[i] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));
-        dst.c2[i] = make_float4(0.f, __uint_as_float((uint32_t)ST_DONE), __uint_as_float(0u), __uint_as_float(0xFFFFFFFFu));
-    }
-    if (threadIdx.x == 0) {
-        const uint32_t first = blockIdx.x * kBlock;
-        dst.chunk_rays[blockIdx.x] = n_live > first ? (n_live - first < (uint32_t)kBlock ? n_live - first : (uint32_t)kBlock) : 0u;
-        dst.block_chunk[2 * blockIdx.x] = src.n_samples;          // nothing left to hand out
-        dst.block_chunk[2 * blockIdx.x + 1] = src.n_samples;
-    }
+    if (ctr) hipLaunchKernelGGL(wf_flush_leftover_kernel<true>, dim3(w.stage_blocks), dim3(kBlock), 0, s, w, cam, ctr);
+    else hipLaunchKernelGGL(wf_flush_leftover_kernel<false>, dim3(w.stage_blocks), dim3(kBlock), 0, s, w, cam, ctr);
 }
 
-// src: the lane's current pool; dst: arrays of a pool of dst.n_slots >= live slots (same counters and staging)
-void launch_wf_repack(const WfParams& src, const WfParams& dst, hipStream_t s)
-{
-    const int n_blocks = src.n_slots / kBlock;
-    uint32_t* chunk_base = src.bsdf_count;
-    uint32_t* live_list = src.bsdf_queue;
-    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, src.counters, src.chunk_rays, src.chunk_list, n_blocks, (const uint32_t*)src.block_chunk, src.n_samples);
-    hipLaunchKernelGGL(wf_drain_plan_kernel, dim3(1), dim3(kPlanThreads), 0, s, src.counters, src.chunk_rays, src.chunk_list, chunk_base);
-    hipLaunchKernelGGL(wf_drain_gather_kernel, dim3(n_blocks), dim3(kBlock), 0, s, src, chunk_base, live_list);
-    hipLaunchKernelGGL(wf_repack_kernel, dim3(dst.n_slots / kBlock), dim3(kBlock), 0, s, src, dst, live_list);
-}
-
+// w as for the iteration that would come next; max_paths: an upper bound of the records in both queues
 void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int max_paths, DCounters* ctr, hipStream_t s)
 {
-    const int n_blocks = w.n_slots / kBlock;
-    // the stage queues are idle now: their arrays hold the per-block bases and the dense list of slots
-    uint32_t* chunk_base = w.bsdf_count;
-    uint32_t* drain_list = w.bsdf_queue;
-    hipLaunchKernelGGL(wf_plan_extend_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, n_blocks, (const uint32_t*)w.block_chunk, w.n_samples);
-    hipLaunchKernelGGL(wf_drain_plan_kernel, dim3(1), dim3(kPlanThreads), 0, s, w.counters, w.chunk_rays, w.chunk_list, chunk_base);
-    hipLaunchKernelGGL(wf_drain_gather_kernel, dim3(n_blocks), dim3(kBlock), 0, s, w, chunk_base, drain_list);
+    hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(kBlock), 0, s, w.counters, (const uint32_t*)w.wg_chunk, w.stage_blocks, w.n_samples);
     int max_blocks = (max_paths + kBlock - 1) / kBlock;
-    if (max_blocks > n_blocks) max_blocks = n_blocks;
     if (max_blocks < 1) max_blocks = 1;
-    if (ctr && w.count_wide && S.wide) hipLaunchKernelGGL((wf_drain_kernel<true, true>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
-    else if (ctr) hipLaunchKernelGGL((wf_drain_kernel<true, false>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
-    else if (S.wide) hipLaunchKernelGGL((wf_drain_kernel<false, true>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
-    else hipLaunchKernelGGL((wf_drain_kernel<false, false>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, drain_list, ctr);
+    if (ctr && w.count_wide && S.wide) hipLaunchKernelGGL((wf_drain_kernel<true, true>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, ctr);
+    else if (ctr) hipLaunchKernelGGL((wf_drain_kernel<true, false>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, ctr);
+    else if (S.wide) hipLaunchKernelGGL((wf_drain_kernel<false, true>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, ctr);
+    else hipLaunchKernelGGL((wf_drain_kernel<false, false>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, ctr);
 }
 
 // adds frames [first, first + count) of the lane's staged chunk to its pixels

@@ -23,7 +23,7 @@ PT_NOALLOC_MAX_RAYS = 262144     # include/pt_capi.h
 EXPORTS = [
     'pt_last_error', 'pt_create', 'pt_destroy', 'pt_set_stream', 'pt_init', 'pt_clear_accum', 'pt_upload_triangles',
     'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_render_frame_async', 'pt_frame_fetch', 'pt_set_frame_lookahead', 'pt_upload_texture', 'pt_upload_envmap',
-    'pt_set_sky_mode', 'pt_set_env_guides', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_set_repack', 'pt_wavefront_stats', 'pt_set_lanes', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_group_create', 'pt_group_frames', 'pt_group_render', 'pt_group_destroy', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
+    'pt_set_sky_mode', 'pt_set_env_guides', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_wavefront_stats', 'pt_set_lanes', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_group_create', 'pt_group_frames', 'pt_group_render', 'pt_group_destroy', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
     'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_save_exr', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
     'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_trace_closest_noalloc_dev', 'pt_debug_words', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
     'pt_detmath_probe', 'pt_bsdf_probe', 'pt_unorm8_probe', 'pt_set_texture_packing', 'pt_read_obj', 'pt_read_obj_general', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
@@ -255,13 +255,10 @@ class Renderer:
     def set_frame_lookahead(self, max_frames):
         check(lib().pt_set_frame_lookahead(self.h, C.c_int(max_frames)))
 
-    def set_repack(self, percent):
-        check(lib().pt_set_repack(self.h, C.c_int(percent)))
-
     def wavefront_stats(self):
         it, rp = C.c_uint64(0), C.c_uint64(0)
         check(lib().pt_wavefront_stats(self.h, C.byref(it), C.byref(rp)))
-        return {'iterations': it.value, 'repacks': rp.value}
+        return {'iterations': it.value, 'drains': rp.value}
 
     def set_lanes(self, lanes):
         check(lib().pt_set_lanes(self.h, C.c_int(lanes)))

@@ -180,10 +180,9 @@ int pt_set_env_guides(pt_ctx* ctx, int on, int* verified_out);           /* on (
 
 /* ---- headless rendering (replaces the window loop, main.cpp:247-296) ---- */
 int pt_set_mode(pt_ctx* ctx, int mode);                                 /* PT_MODE_*; both modes give identical accumulators */
-int pt_set_pool(pt_ctx* ctx, int slots, int chunk_frames);              /* wavefront pool size (default 16777216 path slots) and frames per staging chunk (default 512; one float per pixel and frame of a chunk is held, and each chunk pays one ramp-up and run-down of the pool) */
+int pt_set_pool(pt_ctx* ctx, int slots, int chunk_frames);              /* wavefront pool size (samples in flight, default 16777216) and frames per staging chunk (default 512; one float per pixel and frame of a chunk is held, and each chunk pays one ramp-up and run-down of the pool) */
 int pt_set_drain(pt_ctx* ctx, int max_rays);                            /* wavefront mode: once every sample is started and at most max_rays paths remain, finish them in one kernel (0 = never) */
-int pt_set_repack(pt_ctx* ctx, int percent);                            /* wavefront mode: once every sample is started, move the live path slots together whenever they fill at most this percentage of the pool (0 = never, default 50); same accumulator bits */
-int pt_wavefront_stats(pt_ctx* ctx, uint64_t* iterations_out, uint64_t* repacks_out); /* wavefront mode: stage-kernel iterations issued and pool repacks done since the context was created (either pointer may be null) */
+int pt_wavefront_stats(pt_ctx* ctx, uint64_t* iterations_out, uint64_t* drains_out); /* wavefront mode: stage-kernel iterations issued and drain kernels run since the context was created (either pointer may be null) */
 int pt_set_lanes(pt_ctx* ctx, int lanes);                                /* wavefront mode: number of concurrent lanes (streams), each with a share of the pool and of the pixels; default: 2 for renders of three million samples or more, else 1; same accumulator bits */
 int pt_set_extend_tuning(pt_ctx* ctx, int refill_lanes, int leaf_vote, int blocks_per_cu); /* traversal kernel: idle lanes before a refill, lanes waiting at leaves before a leaf pass, resident workgroups per CU */
 int pt_set_node_width(pt_ctx* ctx, int width, int leaf_merge);         /* production traversal: 4-wide (default) or binary compact nodes; subtrees of <= leaf_merge triangles (default 2) become one wide leaf at the next BVH upload; a tree too deep for the 4-wide stack uses binary */

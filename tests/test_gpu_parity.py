@@ -457,7 +457,7 @@ def test_full_size_render_properties():
     r.clear_accum()
     r.render(P, 0, 3)
     assert np.array_equal(bits(r.read_accum()), bits(wave))
-    # 25 million samples: slots are reused many times, both lanes run, the pool is repacked and drained
+    # 25 million samples: lanes start new samples many times over, both lanes run, the last paths are drained
     r.clear_accum()
     r.render(P, 0, 12)
     single = r.read_accum()
@@ -465,7 +465,7 @@ def test_full_size_render_properties():
     r.clear_accum()
     r.render(P, 0, 12)
     assert np.array_equal(bits(r.read_accum()), bits(single))
-    assert r.wavefront_stats()['repacks'] >= 1
+    assert r.wavefront_stats()['drains'] >= 1
     r.close()
     assert np.isfinite(wave).all() and wave.min() >= 0 and wave.mean() > 0.01
     # oracle on a sparse sample of pixels (a few hundred single-pixel evaluations)
@@ -634,28 +634,27 @@ def test_one_and_two_lanes_agree_and_odd_frame_counts():
         r.close()
 
 
-def test_repacked_pool_gives_the_same_image():
-    """Once every sample is started, the slots that still carry a path are moved together (into the lane's other
-    pool, and back at the next repack). With the drain kernel off the render runs down through many repacks; the
-    accumulator and every counter must be those of the oracle, on one lane and on two, with and without leftover
-    sample ids in the workgroups' chunks at the time the global cursor runs out."""
+def test_run_down_of_the_queues_gives_the_same_image():
+    """Once the global hand-out of sample ids has run dry, the ids that workgroups still hold in their chunks are
+    started all at once and the queues then thin out until they are empty (drain kernel off) or short enough for
+    the drain kernel. The accumulator and every counter must be those of the oracle, on one lane and on two, for
+    pools far larger than the render, far smaller, and smaller than one staging chunk's frame."""
     b = util.atrium(detail=0.3, env_size=(64, 32))
     P = scenes.atrium_params(ptamd.default_params(72, 40))
     want, st = orc.render(b.oracle(P), P, 0, 6, 24)
-    for lanes, pool, percent, drain in ((1, (1 << 20, 64), 90, 0), (2, (1 << 20, 64), 50, 0), (1, (2048, 64), 100, 0), (2, (4096, 2), 75, 64)):
+    for lanes, pool, drain in ((1, (1 << 20, 64), 0), (2, (1 << 20, 64), 0), (1, (2048, 64), 0), (2, (4096, 2), 64), (1, (256, 64), 0), (1, (768, 64), 300)):
         r = b.renderer(P)
         r.set_lanes(lanes)
         r.set_pool(*pool)
         r.set_drain(drain)
-        r.set_repack(percent)
         r.set_max_bounces(24)
         r.enable_counters(True)
         r.render(P, 0, 6)
         _assert_radiance(r.read_accum(), want)
         ctr = r.counters()
         for k in ('rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples'):
-            assert ctr[k] == st[k], (k, lanes, pool, percent)
-        assert r.wavefront_stats()['repacks'] >= 2, (lanes, pool, percent)
+            assert ctr[k] == st[k], (k, lanes, pool, drain)
+        assert (r.wavefront_stats()['drains'] >= 1) == (drain > 0), (lanes, pool, drain)
         r.close()
 
 
