@@ -107,6 +107,7 @@ struct pt_ctx {
     float* d_env_tables = nullptr;   // row table [H] followed by column table [H*W]
     uint32_t* d_env_guides = nullptr; // row guide, column guides, one word of verification result
     uint2* d_env_texel_guide = nullptr; // table over the whole range of xi, one word of verification result
+    float4* d_env_sample_table = nullptr; // per texel: what a light sample that lands on it returns
     bool env_guides_ok = false, use_env_guides = true, env_texel_guide_ok = false, use_env_texel_guide = true;
     DScene scene{};
     bool have_tris = false, have_bvh = false, have_mats = false, have_env = false;
@@ -242,6 +243,7 @@ void pt_destroy(pt_ctx* c)
     if (c->d_env_tables) (void)hipFree(c->d_env_tables);
     if (c->d_env_guides) (void)hipFree(c->d_env_guides);
     if (c->d_env_texel_guide) (void)hipFree(c->d_env_texel_guide);
+    if (c->d_env_sample_table) (void)hipFree(c->d_env_sample_table);
     if (c->own_accum) (void)hipFree(c->own_accum);
     if (c->display) (void)hipFree(c->display);
     free_async_frames(c);
@@ -847,6 +849,16 @@ int pt_upload_envmap(pt_ctx* c, const float* rgba, const float* cdf, int w, int 
     c->scene.env_row_table = c->d_env_tables; c->scene.env_col_table = c->d_env_tables + h;
     c->scene.env_rgba = c->d_env; c->scene.env_cdf = c->d_cdf;
     c->scene.env_w = w; c->scene.env_h = h; c->scene.env_sum = sum;
+    // what a light sample returns, per texel (32 bytes each; maps beyond 2^26 texels compute it per sample)
+    c->scene.env_sample_table = nullptr;
+    if (c->d_env_sample_table) { (void)hipFree(c->d_env_sample_table); c->d_env_sample_table = nullptr; }
+    if ((size_t)w * h <= ((size_t)1 << 26)) {
+        HIP_TRY(hipMalloc((void**)&c->d_env_sample_table, (size_t)w * h * 2 * sizeof(float4)));
+        launch_env_sample_table(c->scene, c->d_env_sample_table, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->use_env_guides) c->scene.env_sample_table = c->d_env_sample_table;
+    }
     // guide tables for the two CDF searches, trusted only if they reproduce the bisection at every breakpoint
     c->scene.env_fast = 0; c->scene.env_fast2 = 0;
     c->env_guides_ok = false; c->env_texel_guide_ok = false;
@@ -904,6 +916,7 @@ int pt_set_env_guides(pt_ctx* c, int on, int* verified_out)
     c->use_env_texel_guide = on != 2;        // 2: row and column guides only
     c->scene.env_fast = (c->env_guides_ok && c->use_env_guides) ? 1 : 0;
     c->scene.env_fast2 = (c->env_texel_guide_ok && c->use_env_guides && c->use_env_texel_guide) ? 1 : 0;
+    c->scene.env_sample_table = c->use_env_guides ? c->d_env_sample_table : nullptr;     // 0: every light sample is computed as the reference does
     if (verified_out) *verified_out = (c->env_guides_ok ? 1 : 0) | (c->env_texel_guide_ok ? 2 : 0);
     return PT_OK;
 }
@@ -1018,10 +1031,10 @@ static int stage_blocks_for(const pt_ctx* c, size_t slots)
 static size_t queue_capacity(const pt_ctx* c, size_t slots) { return slots + (size_t)stage_blocks_for(c, slots) * 256; }
 
 // Bytes of a lane's queues: 32 arrays of 16 bytes per entry (two buffers each of the path queue's 3 and the shadow
-// queue's 12, and the two hit arrays), the bsdf list, and the workgroups' sample-id chunks.
+// queue's 12, and the two hit arrays), the bsdf list, the miss list, and the workgroups' sample-id chunks.
 static size_t pool_bytes(size_t capacity, int stage_blocks)
 {
-    size_t b = capacity * (32 * sizeof(float4) + sizeof(uint32_t)) + (size_t)stage_blocks * 2 * sizeof(uint32_t);
+    size_t b = capacity * (32 * sizeof(float4) + 2 * sizeof(uint32_t)) + (size_t)stage_blocks * 2 * sizeof(uint32_t);
     return (b + 255) / 256 * 256;
 }
 
@@ -1039,7 +1052,8 @@ static void pool_layout(pt_ctx::WfLane& L, void* base_ptr, size_t capacity, int 
     }
     w->hitP = take(); w->hitS = take();
     w->bsdf_list = (uint32_t*)p;
-    w->wg_chunk = w->bsdf_list + capacity;
+    w->miss_list = w->bsdf_list + capacity;
+    w->wg_chunk = w->miss_list + capacity;
     w->counters = L.counters;
     w->capacity = (int)capacity;
     w->stage_blocks = stage_blocks;
@@ -1109,6 +1123,7 @@ static int wf_prepare(pt_ctx* c, pt_ctx::WfLane& L, int frames, int lane, int n_
     w->staging = L.staging;
     w->n_samples = (uint32_t)n_samples;
     w->n_pixels = (uint32_t)n_pixels;
+    w->div_pixels = make_fast_div((uint32_t)n_pixels); w->div_tiles_x = make_fast_div((uint32_t)c->W >> 3); w->div_W = make_fast_div((uint32_t)c->W);
     w->px_lane = lane; w->px_lanes = n_lanes;
     w->W = c->W; w->H = c->H;
     w->tiled = (c->W % 8 == 0 && c->H % 8 == 0) ? 1 : 0;

@@ -135,8 +135,15 @@ PT_DEV Taps tex_taps(int w, int h, float u, float v)
     t.ax = x - fx; t.ay = y - fy;
     t.bx = 1.0f - t.ax; t.by = 1.0f - t.ay;
     int ix = (int)fx, iy = (int)fy;
-    int x0 = wrap_(ix, w), x1 = wrap_(ix + 1, w);
-    int y0 = wrap_(iy, h), y1 = wrap_(iy + 1, h);
+    int x0, x1, y0, y1;
+    if (((w & (w - 1)) | (h & (h - 1))) == 0) {
+        // both sizes are powers of two: the non-negative remainder is a mask (same values, no integer divisions)
+        x0 = ix & (w - 1); x1 = (ix + 1) & (w - 1);
+        y0 = iy & (h - 1); y1 = (iy + 1) & (h - 1);
+    } else {
+        x0 = wrap_(ix, w); x1 = wrap_(ix + 1, w);
+        y0 = wrap_(iy, h); y1 = wrap_(iy + 1, h);
+    }
     t.i00 = y0 * w + x0; t.i10 = y0 * w + x1; t.i01 = y1 * w + x0; t.i11 = y1 * w + x1;
     return t;
 }
@@ -461,8 +468,18 @@ PT_DEV void default_mat(Mat& m)          // structs.cuh:75-94
 
 // pathtracer.cu:140-181: what triangleIntersect does after accepting a hit, evaluated once for the
 // final hit of a query (intermediate accepted hits never reach the caller).
+// diagnostic builds (-DPT_STAMPS_PATH=1): section clocks, every pending memory operation drained at each mark
+#ifndef PT_STAMPS_PATH
+#define PT_STAMPS_PATH 0
+#endif
+#if PT_STAMPS_PATH
+#define PT_MARK(st, k) do { if (st) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); (st)[k] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define PT_MARK(st, k) do { } while (0)
+#endif
+
 template <bool COUNT>
-PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& taps, uint32_t& taps_r, bool visibility_only = false)
+PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& taps, uint32_t& taps_r, bool visibility_only = false, unsigned long long* marks = nullptr)
 {
     // visibility_only: the caller is a segment of the visibility walk, which looks at alpha, metallic, specTrans, ior and
     // the medium only (pathtracer.cu:279-295): the roughness, emission and normal maps are not fetched (the counting
@@ -487,6 +504,7 @@ PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& 
     s.m.G = m4.x; s.m.sigA = f3(m4.y, m4.z, m4.w); s.m.sigS = f3(m5.x, m5.y, m5.z);
     int tx_d = __float_as_int(m5.w), tx_r = __float_as_int(m6.x), tx_m = __float_as_int(m6.y);
     int tx_e = __float_as_int(m6.z), tx_n = __float_as_int(m6.w);
+    PT_MARK(marks, 2);
 
     float u = h.u, v = h.v;
     float w = 1.f - u - v;
@@ -503,6 +521,7 @@ PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& 
         s.m.alpha = r.w;
         if (COUNT) taps++;
     }
+    PT_MARK(marks, 3);
     if (tx_r && all) { const DTex tx = S.tex[tx_r - 1]; s.m.rough = tex1_any(tx, px, py); if (COUNT) taps_r++; }
     if (tx_m) { const DTex tx = S.tex[tx_m - 1]; s.m.metal = tex1_any(tx, px, py); if (COUNT) taps_r++; }
     if (tx_e && all) { const DTex tx = S.tex[tx_e - 1]; float r = tex1_any(tx, px, py); s.m.emis = f3(r, r, r); if (COUNT) taps_r++; }
@@ -514,6 +533,7 @@ PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& 
         s.n = to_world(Tn, Bn, s.n, f3(r.x * 2.f - 1.f, r.y * 2.f - 1.f, r.z * 2.f - 1.f));
         if (COUNT) taps++;
     }
+    PT_MARK(marks, 4);
     s.n = ref_if_neg(s.n, -1.0f * d);
 }
 
@@ -865,21 +885,12 @@ PT_DEV void env_search_texel(const DScene& S, float xi, uint32_t& taps_r, int& x
     col = env_bisect<COUNT>(S.env_col_table + (size_t)y * S.env_w, S.env_w, xi, taps_r);
     x = (int)clamp_((float)col, 0.f, (float)(S.env_w - 1));
 }
-template <bool COUNT>
-PT_DEV F2 env_search(const DScene& S, float xi, uint32_t& taps_r)
+// What sampleEnvMap (envmap_cuda.cu:59-74) returns for the texel its searches ended at: direction + pdf; color
+// receives the radiance. Every value depends on the texel alone.
+PT_DEV float4 sample_envmap_texel(const DScene& S, int x, int y, F3& color)
 {
-    int x, y;
-    env_search_texel<COUNT>(S, xi, taps_r, x, y);
     F2 uv = {(float)x / (float)S.env_w, (float)y / (float)S.env_h};
-    return uv;
-}
-// returns direction + pdf; color receives the radiance
-template <bool COUNT>
-PT_DEV float4 sample_envmap(const DScene& S, F3& color, Rng& rng, uint32_t& taps, uint32_t& taps_r)
-{
-    F2 uv = env_search<COUNT>(S, rng_next(rng) * S.env_sum, taps_r);
     float4 r = tex4(S.env_rgba, S.env_w, S.env_h, uv.x, uv.y);
-    if (COUNT) taps++;
     color = f3(r.x, r.y, r.z);
     float pdf = disney::luminance(color) / S.env_sum;
     float phi = uv.x * PT_TWO_PI;
@@ -887,6 +898,23 @@ PT_DEV float4 sample_envmap(const DScene& S, F3& color, Rng& rng, uint32_t& taps
     float sn = pt_sinf(theta);
     if (sn == 0.f) pdf = 0.f;
     return make_float4(-sn * pt_cosf(phi), pt_cosf(theta), -sn * pt_sinf(phi), (pdf * S.env_w * S.env_h) / (PT_TWO_PI * PT_PI * sn));
+}
+// One light sample: a draw, the two searches, then the texel's values, read from the per-texel table made when the
+// map was uploaded (the same function evaluated once per texel: two loads instead of four filtered lookups and
+// four trigonometric functions per sample) or computed on the spot.
+template <bool COUNT>
+PT_DEV float4 sample_envmap(const DScene& S, F3& color, Rng& rng, uint32_t& taps, uint32_t& taps_r)
+{
+    int x, y;
+    env_search_texel<COUNT>(S, rng_next(rng) * S.env_sum, taps_r, x, y);
+    if (COUNT) taps++;
+    if (!COUNT && S.env_sample_table) {
+        const float4* e = S.env_sample_table + 2 * ((size_t)y * S.env_w + x);
+        const float4 dir = e[0], c = e[1];
+        color = f3(c.x, c.y, c.z);
+        return dir;
+    }
+    return sample_envmap_texel(S, x, y, color);
 }
 PT_DEV float sky_hg(float g, float c) { float gg = g * g; return (1. - gg) / pt_dm_pow(1. + gg - 2. * g * c, 1.5); }
 PT_DEV float sky_rayleigh(float u) { return 0.75 * (1. + clamp_(u * u, 0., 1.)); }

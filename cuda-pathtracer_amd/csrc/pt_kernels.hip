@@ -175,6 +175,23 @@ void launch_env_tables(const float* cdf_dev, int w, int h, float* row_table_dev,
     hipLaunchKernelGGL(env_tables_kernel, dim3((w * h + 255) / 256), dim3(256), 0, stream, cdf_dev, w, h, row_table_dev, col_table_dev);
 }
 
+// The light sample of every texel (sample_envmap_texel), evaluated once: (direction, pdf) and (radiance, 0).
+__global__ __launch_bounds__(256) void env_sample_table_kernel(DScene S, float4* __restrict__ table)
+{
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)S.env_w * S.env_h) return;
+    int y = (int)(i / (size_t)S.env_w), x = (int)(i - (size_t)y * S.env_w);
+    F3 color;
+    float4 dir = sample_envmap_texel(S, x, y, color);
+    table[2 * i] = dir;
+    table[2 * i + 1] = make_float4(color.x, color.y, color.z, 0.f);
+}
+void launch_env_sample_table(const DScene& S, float4* table_dev, hipStream_t stream)
+{
+    size_t n = (size_t)S.env_w * S.env_h;
+    hipLaunchKernelGGL(env_sample_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, S, table_dev);
+}
+
 // ---------------------------------------------------------------- environment search guides
 // One workgroup per table (blockIdx 0: the row table, blockIdx 1 + y: row y of the column table).
 // Bucket k covers the xi with (int)(xi * scale) == k; its range runs from the index the search ends at for

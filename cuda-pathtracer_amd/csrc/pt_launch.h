@@ -31,6 +31,7 @@ struct GpuScene {
 };
 int gpu_build_scene(const pt_triangle* tris_dev, int n, int leaf_merge, bool agglomerative, bool top_sah, GpuScene* out, int* tri_idx_host, hipStream_t stream);
 void launch_env_tables(const float* cdf_dev, int w, int h, float* row_table_dev, float* col_table_dev, hipStream_t stream);
+void launch_env_sample_table(const DScene& S, float4* table_dev, hipStream_t stream);
 void launch_env_texel_guide(const DScene& S, uint2* guide_dev, uint32_t* mismatches_dev, hipStream_t stream);
 void launch_env_guides(const DScene& S, uint32_t* row_guide_dev, uint32_t* col_guide_dev, uint32_t* mismatches_dev, hipStream_t stream);
 void launch_bsdf_probe(const pt_material* mats_dev, const int* inside_dev, const float* V_dev, const float* N_dev, const float* L_dev, const uint32_t* pixel_dev,

@@ -90,6 +90,7 @@ struct DScene {
     // One table over the whole range of xi: the bucket of xi gives the row and the column range directly
     // when the bucket lies inside one row (x = row, y = first | last << 16), else x = 0xFFFFFFFF.
     const uint2* env_texel_guide;    // [kEnvTexelBuckets]
+    const float4* env_sample_table;  // [H*W][2] (direction, pdf) and (radiance, 0) of a light sample that lands on the texel, or null
     float env_texel_scale;
     int env_fast2;
     int env_w, env_h;
@@ -139,6 +140,9 @@ enum : int {
     WF_CTR_TAIL_P = 64,         // entries appended to the next path queue so far
     WF_CTR_TAIL_S = 128,        // entries appended to the next shadow queue so far
     WF_CTR_TAIL_B = 192,        // entries of the bsdf list
+    WF_CTR_TAIL_M = 576,        // entries of the miss list
+    WF_CTR_SEG_MISS = 640,      // next segment of the miss list
+    WF_CTR_SEG_VERTEX = 704,    // next segment of the records the resolve stage placed in the next shadow queue
     WF_CTR_RAY_NEXT = 256,      // next block of 256 rays the extend kernel hands to a wave
     WF_CTR_SEG_PATH = 320,      // next 256-record segment of the current path queue / shadow queue / bsdf list a
     WF_CTR_SEG_SHADOW = 384,    //   workgroup of the stage kernel takes
@@ -148,13 +152,27 @@ enum : int {
     WF_CTR_RAY_CHUNKS = 514,    // blocks of 256 rays in both queues together; the first RAY_P_CHUNKS are path rays
     WF_CTR_RAY_P_CHUNKS = 515,
     WF_CTR_LEFTOVER = 516,      // sample ids workgroups still hold in their chunks at the last planning pass
-    WF_CTR_WORDS = 520
+    WF_CTR_WORDS = 712
 };
+// Division of a 32-bit unsigned number by a divisor fixed at launch (Granlund and Montgomery, "Division by invariant
+// integers using multiplication", figure 4.1): exact for every numerator, five integer instructions instead of the
+// thirty-odd of a run-time division.
+struct FastDiv { uint32_t d, m, sh1, sh2; };
+inline FastDiv make_fast_div(uint32_t d)
+{
+    FastDiv f; f.d = d ? d : 1u;
+    uint32_t l = 0;
+    while (l < 32 && ((uint64_t)1 << l) < (uint64_t)f.d) l++;              // ceil(log2 d)
+    f.m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - (uint64_t)f.d)) / (uint64_t)f.d + 1u);
+    f.sh1 = l < 1 ? l : 1u; f.sh2 = l > 0 ? l - 1u : 0u;
+    return f;
+}
 struct WfParams {
     WfPathQueue Pc, Pn;             // current and next path queue
     WfShadowQueue Sc, Sn;           // current and next shadow queue
     float4 *hitP, *hitS;            // (t, triangle, u, v) for the records of the current queues
     uint32_t* bsdf_list;            // positions in the current shadow queue (bit 31 set: in the next one) whose light sample is finished
+    uint32_t* miss_list;            // positions in the current path queue whose ray left the scene
     uint32_t* wg_chunk;             // [stage_blocks][2] cursor/end of the sample-id chunk each persistent workgroup owns
     uint32_t* counters;
     float* staging;                 // n_frames * W * H sample values of the current chunk
@@ -167,6 +185,7 @@ struct WfParams {
     // blocks of 64: this lane owns blocks px_lane, px_lane + px_lanes, ...; n_pixels of them in all.
     int px_lane, px_lanes;
     uint32_t n_pixels;
+    FastDiv div_pixels, div_tiles_x, div_W;       // divisions by n_pixels, W / 8 and W
     int refill_lanes, leaf_vote, extend_blocks;   // extend-kernel tuning (see wf_extend_kernel)
     int count_wide;                               // counting builds: tally the production (wide) walk's own work instead of the reference-order walk
 };

@@ -173,23 +173,28 @@ PT_DEV void start_light(const DScene& S, const DCamera& cam, Path& P, F3 origin,
     P.state = ST_SHADOW;
 }
 
-// One vertex of pathtrace (pathtracer.cu:406-481) up to the point where it needs the next ray.
+// The path ray left the scene (pathtracer.cu:409-425): the environment's radiance, weighted against the light
+// sampling of the last vertex, ends the sample.
 template <bool COUNT>
-PT_DEV void on_path_hit(const DScene& S, const DCamera& cam, Path& P, Surf& info, Tally& tl)
+PT_DEV void on_path_miss(const DScene& S, Path& P, Tally& tl)
+{
+    F3 envc; float envp;
+    if (S.sky_mode == PT_SKY_SUNSKY) { envc = sky_gradient(P.d, ld3(S.sun)); envp = 0.f; }
+    else { float4 e = eval_envmap(S, P.d); envc = f3(e.x, e.y, e.z); envp = e.w; if (COUNT) tl.taps++; }
+    float mis = 1.f;
+    if (P.bounce > 0) mis = power_heuristic(P.pdf, envp);
+    if (!P.surface_scatter) mis = 1.f;
+    if (S.sky_mode == PT_SKY_SUNSKY) mis = 1.f;
+    if (mis > 0.f) P.result += getN(mis * envc * P.thr, P.ch);
+    P.state = ST_DONE;
+}
+
+// One vertex of pathtrace (pathtracer.cu:426-481), given the resolved surface, up to the point where the sample needs
+// its next ray.
+template <bool COUNT>
+PT_DEV void on_path_vertex(const DScene& S, const DCamera& cam, Path& P, Surf& info, Tally& tl)
 {
     info.inside = P.inside;
-    if (!info.hit) {
-        F3 envc; float envp;
-        if (S.sky_mode == PT_SKY_SUNSKY) { envc = sky_gradient(P.d, ld3(S.sun)); envp = 0.f; }
-        else { float4 e = eval_envmap(S, P.d); envc = f3(e.x, e.y, e.z); envp = e.w; if (COUNT) tl.taps++; }
-        float mis = 1.f;
-        if (P.bounce > 0) mis = power_heuristic(P.pdf, envp);
-        if (!P.surface_scatter) mis = 1.f;
-        if (S.sky_mode == PT_SKY_SUNSKY) mis = 1.f;
-        if (mis > 0.f) P.result += getN(mis * envc * P.thr, P.ch);
-        P.state = ST_DONE;
-        return;
-    }
     if (COUNT) tl.verts++;
     info.m.rough = pt_fmaxf(info.m.rough, 0.0001f);
     P.surface_scatter = false;
@@ -218,6 +223,14 @@ PT_DEV void on_path_hit(const DScene& S, const DCamera& cam, Path& P, Surf& info
     }
     P.o = P.o + P.d * 0.01f;
     roulette_and_advance(P, cam);
+}
+
+// pathtracer.cu:406-481: what a path ray's closest hit leads to
+template <bool COUNT>
+PT_DEV void on_path_hit(const DScene& S, const DCamera& cam, Path& P, Surf& info, Tally& tl)
+{
+    if (!info.hit) { on_path_miss<COUNT>(S, P, tl); return; }
+    on_path_vertex<COUNT>(S, cam, P, info, tl);
 }
 
 // One segment of visibility (pathtracer.cu:279-295)

@@ -6,9 +6,13 @@
 //              current ones and resets the per-iteration counters
 //   extend   : closest hit for the pending ray of every record of both queues (camera, bounce and shadow-walk
 //              rays alike): persistent waves over 4-wide quantized nodes, traversal stack in LDS
-//   path     : consumes the hits of the path queue: miss (environment, sample finished) or vertex (material
-//              resolve, emission, medium / surface event, light-sample set-up); a vertex that drew a light sample
-//              moves to the next shadow queue, a ray that passed through to the next path queue
+//   resolve  : consumes the hits of the path queue: shading normal and material values at the hit (the chain of
+//              dependent gathers hit -> triangle -> material -> textures), written into a fresh record of the next
+//              shadow queue; rays that left the scene are listed for the miss stage
+//   vertex   : the rest of the vertex for those records (medium / surface event, alpha test, light-sample set-up);
+//              a vertex that drew a light sample completes its record, a ray that passed through moves to the next
+//              path queue
+//   miss     : environment radiance for the listed rays; their samples are finished and the lanes start new ones
 //   shadow   : consumes the hits of the shadow queue, one segment of the visibility walk each (the light-weight
 //              kernel: alpha, metallic, transmission, ior and the medium of the surface it hit); a walk that goes
 //              on moves to the next shadow queue, a finished one is listed for the bsdf stage
@@ -61,24 +65,30 @@ struct SampleId { int x, y, frame; uint32_t pixel; uint32_t stage_index; };
 // Position of a lane-local pixel number in the image. Pixels are walked in 8x8 tiles when the image allows it,
 // so that the 64 samples a wave takes together form one tile (coherent camera rays), else row by row; blocks of
 // 64 consecutive pixels of that order are dealt to the lanes in turn.
+PT_DEV uint32_t fast_div(uint32_t n, const FastDiv& f)
+{
+    const uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
 PT_DEV void lane_pixel(const WfParams& w, uint32_t q, int& x, int& y)
 {
     uint32_t p = ((q >> 6) * (uint32_t)w.px_lanes + (uint32_t)w.px_lane) * 64u + (q & 63u);
     if (w.tiled) {
-        uint32_t tiles_x = (uint32_t)w.W >> 3;
         uint32_t tile = p >> 6, l = p & 63u;
-        x = (int)((tile % tiles_x) * 8 + (l & 7u));
-        y = (int)((tile / tiles_x) * 8 + (l >> 3));
+        uint32_t ty = fast_div(tile, w.div_tiles_x), tx = tile - ty * w.div_tiles_x.d;
+        x = (int)(tx * 8 + (l & 7u));
+        y = (int)(ty * 8 + (l >> 3));
     } else {
-        x = (int)(p % (uint32_t)w.W);
-        y = (int)(p / (uint32_t)w.W);
+        uint32_t py = fast_div(p, w.div_W);
+        x = (int)(p - py * w.div_W.d);
+        y = (int)py;
     }
 }
 // sample id -> (pixel, frame): the lane's pixels frame after frame
 PT_DEV SampleId decode_sample(const WfParams& w, uint32_t s)
 {
     SampleId id;
-    uint32_t fr = s / w.n_pixels, q = s - fr * w.n_pixels;
+    uint32_t fr = fast_div(s, w.div_pixels), q = s - fr * w.n_pixels;
     lane_pixel(w, q, id.x, id.y);
     id.frame = w.frame_begin + (int)fr;
     id.pixel = (uint32_t)(id.x + id.y * w.W);
@@ -220,15 +230,15 @@ PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, Path& P
 
 // Queue positions for the lanes of a workgroup that append to a queue: the lanes for which `want` holds get
 // consecutive positions, in thread order, from one atomic on the queue's tail word. Every thread of the workgroup
-// must call it (it synchronises); the others get kNone. Up to three queues at once share the two barriers.
-struct Appends { bool want[3]; uint32_t* tail[3]; uint32_t pos[3]; };
+// must call it (it synchronises); the others get kNone. Up to four queues at once share the barriers.
+struct Appends { bool want[4]; uint32_t* tail[4]; uint32_t pos[4]; };
 template <int N>
 PT_DEV void reserve(Appends& a)
 {
-    __shared__ uint32_t s_cnt[3][kBlock / 64];
-    __shared__ uint32_t s_base[3];
+    __shared__ uint32_t s_cnt[4][kBlock / 64];
+    __shared__ uint32_t s_base[4];
     const int wid = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63u);
-    unsigned long long m[3];
+    unsigned long long m[4];
 #pragma unroll
     for (int k = 0; k < N; k++) {
         m[k] = __ballot(a.want[k]);
@@ -338,9 +348,9 @@ __global__ __launch_bounds__(kBlock) void wf_plan_kernel(uint32_t* __restrict__ 
         for (int j = 0; j < kBlock / 64; j++) leftover += s_left[j];
         const uint32_t nP = counters[WF_CTR_TAIL_P], nS = counters[WF_CTR_TAIL_S];
         counters[WF_CTR_N_P] = nP; counters[WF_CTR_N_S] = nS;
-        counters[WF_CTR_TAIL_P] = 0; counters[WF_CTR_TAIL_S] = 0; counters[WF_CTR_TAIL_B] = 0;
+        counters[WF_CTR_TAIL_P] = 0; counters[WF_CTR_TAIL_S] = 0; counters[WF_CTR_TAIL_B] = 0; counters[WF_CTR_TAIL_M] = 0;
         counters[WF_CTR_RAY_NEXT] = 0;
-        counters[WF_CTR_SEG_PATH] = 0; counters[WF_CTR_SEG_SHADOW] = 0; counters[WF_CTR_SEG_BSDF] = 0;
+        counters[WF_CTR_SEG_PATH] = 0; counters[WF_CTR_SEG_SHADOW] = 0; counters[WF_CTR_SEG_BSDF] = 0; counters[WF_CTR_SEG_MISS] = 0; counters[WF_CTR_SEG_VERTEX] = 0;
         counters[WF_CTR_RAY_P_CHUNKS] = (nP + kBlock - 1) / kBlock;
         counters[WF_CTR_RAY_CHUNKS] = (nP + kBlock - 1) / kBlock + (nS + kBlock - 1) / kBlock;
         counters[WF_CTR_LEFTOVER] = leftover;
@@ -657,51 +667,153 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     flush_tally<COUNT>(ctr, tl, 0);
 }
 
-// ---------------------------------------------------------------- path
-// One vertex of pathtrace (pathtracer.cu:406-481) for every record of the path queue, up to the point where the
-// sample needs its next ray. Persistent workgroups take 256-record segments in turn.
-#ifndef PT_PATH_WAVES
-#define PT_PATH_WAVES 3
-#endif
+// ---------------------------------------------------------------- resolve
+// First half of a path vertex (what triangleIntersect does for the hit it keeps, pathtracer.cu:140-181): shading
+// normal and material values at the hit, up to five filtered texture lookups. It is a chain of dependent gathers
+// (hit -> triangle -> material -> texture -> texels) that needs the ray direction but nothing else of the sample,
+// so it runs as a kernel of its own with few registers and many waves per SIMD to hide the chain. Every hit gets
+// its position in the next shadow queue here, and the resolved surface is written straight into that record's
+// vertex arrays; the vertex stage fills in the rest. Rays that left the scene are listed for the miss stage.
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_PATH_WAVES))) void wf_path_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+__global__ __launch_bounds__(kBlock) void wf_resolve_kernel(WfParams w, DScene S, DCounters* ctr)
 {
     const uint32_t n_in = w.counters[WF_CTR_N_P];
     const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
     Tally tl = {0, 0, 0, 0, 0, 0, 0};
-    uint32_t nsamples = 0;
     for (;;) {
         const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_PATH);
         if (seg >= n_seg) break;                    // uniform over the workgroup
         const uint32_t i = seg * kBlock + threadIdx.x;
         const bool have = i < n_in;
+        Hit h; h.t = 0.f; h.tri = PT_NO_TRI; h.u = 0.f; h.v = 0.f;
+        if (have) { float4 h4 = w.hitP[i]; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w; }
+        const bool hit = have && h.tri != PT_NO_TRI;
+        Surf info;
+        int mat_index = 0;
+        if (hit) {
+            float4 d4 = w.Pc.c1[i];
+            resolve_hit<COUNT>(S, h, f3(d4.x, d4.y, d4.z), info, tl.taps, tl.taps_r, false);
+            info.m.rough = pt_fmaxf(info.m.rough, 0.0001f);         // pathtracer.cu:427
+            mat_index = S.tri_ref[h.tri].matIndex;
+        }
+        Appends a;
+        a.want[0] = hit; a.tail[0] = w.counters + WF_CTR_TAIL_S;
+        a.want[1] = have && !hit; a.tail[1] = w.counters + WF_CTR_TAIL_M;
+        reserve<2>(a);
+        if (hit) {
+            const uint32_t j = a.pos[0];
+            const Mat& m = info.m;
+            // (hit distance, material, -, path record): what the vertex stage needs beside the vertex arrays
+            w.Sn.so[j] = make_float4(h.t, __int_as_float(mat_index), 0.f, __uint_as_float(i));
+            w.Sn.e0[j] = make_float4(m.base.x, m.base.y, m.base.z, m.rough);
+            w.Sn.e1[j] = make_float4(m.emis.x, m.emis.y, m.emis.z, m.aniso);
+            w.Sn.e2[j] = make_float4(m.metal, m.subsurf, m.sheen, m.coat);
+            w.Sn.e3[j] = make_float4(m.coat_rough, m.strans, m.ior, m.G);
+            w.Sn.e4[j] = make_float4(info.n.x, info.n.y, info.n.z, m.alpha);
+        }
+        if (a.want[1]) w.miss_list[a.pos[1]] = i;
+    }
+    flush_tally<COUNT>(ctr, tl, 0);
+}
+
+// ---------------------------------------------------------------- vertex
+// Second half of a path vertex (pathtracer.cu:426-481) for the records the resolve stage placed in the next shadow
+// queue: medium event, alpha test, light-sample set-up. A vertex that drew a light sample completes its record
+// where it is; a ray that passed through the surface moves on to the next path queue and leaves a dead record.
+#ifndef PT_VERTEX_WAVES
+#define PT_VERTEX_WAVES 4
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTEX_WAVES))) void wf_vertex_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+{
+    const uint32_t n_in = w.counters[WF_CTR_TAIL_S];      // the records the resolve stage allocated; nothing else has appended yet
+    const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
+    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t nsamples = 0;
+    for (;;) {
+        const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_VERTEX);
+        if (seg >= n_seg) break;
+        const uint32_t j = seg * kBlock + threadIdx.x;
+        const bool have = j < n_in;
         Path P;
         SampleId id = {0, 0, 0, 0u, 0u};
         uint32_t sample = kNone;
         P.state = ST_DONE;
         bool finished = false;
         if (have) {
-            sample = load_path(w.Pc, i, w, P, id);
-            float4 h4 = w.hitP[i];
-            Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
+            const float4 link = w.Sn.so[j];
+            const float4 a = w.Sn.e0[j], b = w.Sn.e1[j], c = w.Sn.e2[j], d = w.Sn.e3[j], e = w.Sn.e4[j];
+            sample = load_path(w.Pc, __float_as_uint(link.w), w, P, id);
             Surf info;
-            resolve_hit<COUNT>(S, h, P.d, info, tl.taps, tl.taps_r, false);
-            on_path_hit<COUNT>(S, cam, P, info, tl);
+            info.t = link.x; info.hit = true; info.inside = false;
+            Mat& m = info.m;
+            m.base = f3(a.x, a.y, a.z); m.rough = a.w;
+            m.emis = f3(b.x, b.y, b.z); m.aniso = b.w;
+            m.metal = c.x; m.subsurf = c.y; m.sheen = c.z; m.coat = c.w;
+            m.coat_rough = d.x; m.strans = d.y; m.ior = d.z; m.G = d.w;
+            info.n = f3(e.x, e.y, e.z); m.alpha = e.w;
+            m.sigA = f3(0.f, 0.f, 0.f); m.sigS = f3(0.f, 0.f, 0.f);
+            if (P.inside) {         // the medium this path travels in is described by the surface it meets (pathtracer.cu:432-433)
+                const DMat& M = S.mats[__float_as_int(link.y)];
+                m.sigA = f3(M.sigA[0], M.sigA[1], M.sigA[2]); m.sigS = f3(M.sigS[0], M.sigS[1], M.sigS[2]);
+            }
+            on_path_vertex<COUNT>(S, cam, P, info, tl);
             finished = P.state == ST_DONE;
         }
         finish_and_regenerate<COUNT>(w, cam, P, sample, id, finished, nsamples);
-        // where the record goes: a new or passed-through path ray to the next path queue; a vertex with its light
-        // sample to the next shadow queue, and, when there is no visibility walk to wait for (sun/sky mode draws no
-        // light sample, pathtracer.cu:346-380 has none), straight onto this iteration's bsdf list as well
+        // where the sample goes: a new or passed-through path ray to the next path queue; a vertex with its light sample
+        // stays in this record, and, when there is no visibility walk to wait for (sun/sky mode draws no light sample),
+        // goes straight onto this iteration's bsdf list as well
         const bool alive = have && P.state != ST_DONE;
+        const bool stays = alive && P.state != ST_PATH;
+        Appends ap;
+        ap.want[0] = alive && P.state == ST_PATH; ap.tail[0] = w.counters + WF_CTR_TAIL_P;
+        ap.want[1] = alive && P.state == ST_AFTER; ap.tail[1] = w.counters + WF_CTR_TAIL_B;
+        reserve<2>(ap);
+        if (ap.want[0]) store_path(w.Pn, ap.pos[0], P, sample);
+        if (stays) {
+            w.Sn.so[j] = make_float4(P.so.x, P.so.y, P.so.z, 0.f);
+            w.Sn.sd[j] = make_float4(P.sd.x, P.sd.y, P.sd.z, __int_as_float(P.state == ST_SHADOW ? 1 : 0));
+            store_core(w.Sn.c0, w.Sn.c1, w.Sn.c2, j, P, sample);
+            w.Sn.d0[j] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
+            w.Sn.d1[j] = make_float4(P.env_color.x, P.env_color.y, P.env_color.z, 0.f);
+        } else if (have) {
+            w.Sn.sd[j] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));       // a dead record: no ray, no sample
+        }
+        if (ap.want[1]) w.bsdf_list[ap.pos[1]] = j | 0x80000000u;
+    }
+    flush_tally<COUNT>(ctr, tl, nsamples);
+}
+
+// ---------------------------------------------------------------- miss
+// The path rays that left the scene (pathtracer.cu:409-425): environment radiance, then every lane's sample is
+// finished and the lane starts a new one. Dense in both respects, which the same work was not as a branch of the
+// path stage: one ray in six misses there, and only those lanes start new samples.
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void wf_miss_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+{
+    const uint32_t n_in = w.counters[WF_CTR_TAIL_M];
+    const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
+    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    uint32_t nsamples = 0;
+    for (;;) {
+        const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_MISS);
+        if (seg >= n_seg) break;
+        const uint32_t k = seg * kBlock + threadIdx.x;
+        const bool have = k < n_in;
+        Path P;
+        SampleId id = {0, 0, 0, 0u, 0u};
+        uint32_t sample = kNone;
+        P.state = ST_DONE;
+        if (have) {
+            sample = load_path(w.Pc, w.miss_list[k], w, P, id);
+            on_path_miss<COUNT>(S, P, tl);
+        }
+        finish_and_regenerate<COUNT>(w, cam, P, sample, id, have, nsamples);
         Appends a;
-        a.want[0] = alive && P.state == ST_PATH; a.tail[0] = w.counters + WF_CTR_TAIL_P;
-        a.want[1] = alive && P.state != ST_PATH; a.tail[1] = w.counters + WF_CTR_TAIL_S;
-        a.want[2] = alive && P.state == ST_AFTER; a.tail[2] = w.counters + WF_CTR_TAIL_B;
-        reserve<3>(a);
+        a.want[0] = have && P.state == ST_PATH; a.tail[0] = w.counters + WF_CTR_TAIL_P;
+        reserve<1>(a);
         if (a.want[0]) store_path(w.Pn, a.pos[0], P, sample);
-        if (a.want[1]) store_shadow(w.Sn, a.pos[1], P, sample);
-        if (a.want[2]) w.bsdf_list[a.pos[2]] = a.pos[1] | 0x80000000u;
     }
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
@@ -1063,12 +1175,16 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
     else hipLaunchKernelGGL((wf_extend_kernel<false, false>), dim3(ext_blocks), block, 0, s, w, S, ctr);
     if (ext1) (void)hipEventRecord(ext1, s);
     if (ctr) {
+        hipLaunchKernelGGL(wf_resolve_kernel<true>, stage, block, 0, s, w, S, ctr);
+        hipLaunchKernelGGL(wf_vertex_kernel<true>, stage, block, 0, s, w, S, cam, ctr);      // before anything else appends to the next shadow queue
+        hipLaunchKernelGGL(wf_miss_kernel<true>, stage, block, 0, s, w, S, cam, ctr);
         hipLaunchKernelGGL(wf_shadow_kernel<true>, stage, block, 0, s, w, S, cam, ctr);
-        hipLaunchKernelGGL(wf_path_kernel<true>, stage, block, 0, s, w, S, cam, ctr);
         hipLaunchKernelGGL(wf_bsdf_kernel<true>, stage, block, 0, s, w, S, cam, ctr);
     } else {
+        hipLaunchKernelGGL(wf_resolve_kernel<false>, stage, block, 0, s, w, S, ctr);
+        hipLaunchKernelGGL(wf_vertex_kernel<false>, stage, block, 0, s, w, S, cam, ctr);      // before anything else appends to the next shadow queue
+        hipLaunchKernelGGL(wf_miss_kernel<false>, stage, block, 0, s, w, S, cam, ctr);
         hipLaunchKernelGGL(wf_shadow_kernel<false>, stage, block, 0, s, w, S, cam, ctr);
-        hipLaunchKernelGGL(wf_path_kernel<false>, stage, block, 0, s, w, S, cam, ctr);
         hipLaunchKernelGGL(wf_bsdf_kernel<false>, stage, block, 0, s, w, S, cam, ctr);
     }
 }

@@ -176,7 +176,7 @@ int pt_upload_texture(pt_ctx* ctx, const float* texels, int w, int h, int comps,
 int pt_set_texture_packing(pt_ctx* ctx, int on);                        /* on (default): textures whose values are all exactly k/255 are stored as bytes; the sampled values are the same */
 int pt_upload_envmap(pt_ctx* ctx, const float* rgba, const float* cdf, int w, int h, float sum, pt_params* params_io); /* generateCUDAenvmap + transfertToParams */
 int pt_set_sky_mode(pt_ctx* ctx, int mode);
-int pt_set_env_guides(pt_ctx* ctx, int on, int* verified_out);           /* on (default 1): sampleEnvMap's two bisections (envmap_cuda.cu:28-57) are answered from guide tables (one over the whole range of the random number that names row and column range at once; a row table and per-row column tables behind it) when a check of every breakpoint at upload found the results identical; 2 = without the whole-range table, 0 = plain bisections. verified_out: bit 0 the row/column tables passed for the current map, bit 1 the whole-range table */
+int pt_set_env_guides(pt_ctx* ctx, int on, int* verified_out);           /* on (default 1): sampleEnvMap's two bisections (envmap_cuda.cu:28-57) are answered from guide tables (one over the whole range of the random number that names row and column range at once; a row table and per-row column tables behind it) when a check of every breakpoint at upload found the results identical; 2 = without the whole-range table, 0 = plain bisections. With 1 or 2 the values a light sample returns for the texel it lands on (radiance, direction, pdf: envmap_cuda.cu:62-73, functions of the texel alone) are read from a table computed per texel at upload by the same code; with 0 they are computed per sample. verified_out: bit 0 the row/column tables passed for the current map, bit 1 the whole-range table */
 
 /* ---- headless rendering (replaces the window loop, main.cpp:247-296) ---- */
 int pt_set_mode(pt_ctx* ctx, int mode);                                 /* PT_MODE_*; both modes give identical accumulators */
