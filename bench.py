@@ -10,11 +10,16 @@ per-GPU accumulators on rank 0 (RCCL reduce, N > 1 only), resolve to RGBA8.  Ran
 frame ranges (sample partition), so work per GPU is fixed as N grows: weak scaling.
 --total-spp S fixes the samples per pixel of a step over all GPUs instead (rank r renders frames
 [r*S/N, (r+1)*S/N) of each step): strong scaling, the form of the 4096-spp and 1024-spp configurations.
---workload soup renders the 10-million-triangle soup (tree built on the GPU), whose 2.4 GB of nodes and
+--workload soup renders the 10-million-triangle soup (tree built on the GPU), whose 0.8 GB of nodes and
 triangle records do not fit any cache: the case in which HBM bounds the traversal kernel.
+--workload sunsky renders the atrium with glossy metal and glass materials under the sun/sky model.
+
+With --gpus N > 1 and no launcher around it (WORLD_SIZE unset) the script starts itself N times under
+torch.distributed.run as a child process and relays rank 0's line and the exit status.
 
 Prints one JSON line: metric Mrays/s (a ray is one closest-hit query: camera, bounce or shadow-walk
-segment), with samples/s, the roofline of the dominant kernel and the CPU oracle timed beside it.
+segment), with samples/s, the roofline of the dominant kernel, a table of every stage kernel, and the CPU
+oracle timed beside it.
 """
 import argparse
 import json
@@ -29,6 +34,9 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E datasheet peak
+STAGES = ('extend', 'resolve', 'vertex', 'miss', 'shadow', 'bsdf')
+KERNEL_NAMES = {'extend': 'wf_extend_kernel', 'resolve': 'wf_resolve_kernel', 'vertex': 'wf_vertex_kernel', 'miss': 'wf_miss_kernel',
+                'shadow': 'wf_shadow_kernel', 'bsdf': 'wf_bsdf_kernel'}
 
 
 def algorithmic_bytes(c):
@@ -37,6 +45,54 @@ def algorithmic_bytes(c):
     (material); 64 per 4-channel bilinear lookup, 16 per 1-channel lookup; 24 per sample (accumulator)."""
     return (40 * c['rays'] + 32 * c['box_tests'] + 48 * c['tri_tests'] + 128 * c['shade_vertices']
             + 64 * c['tex_taps'] + 16 * c['tex_taps_r'] + 24 * c['samples'])
+
+
+def requested_bytes(c, packed_textures):
+    """Bytes each stage kernel asks the memory system for over the counted frames, from the records it reads and
+    writes (cuda-pathtracer_amd/csrc/pt_wavefront.hip) and the tallies of the instrumented run: c['path_rays'] path rays
+    of which c['shade_vertices'] hit a surface, the rest leave the scene; c['rays'] - c['path_rays'] segments of
+    visibility walks; one bsdf evaluation per vertex."""
+    hits = c['shade_vertices']
+    misses = max(c['path_rays'] - hits, 0.0)
+    segments = max(c['rays'] - c['path_rays'], 0.0)
+    tap4, tap1 = (16, 4) if packed_textures else (64, 16)       # four texels of a filtered lookup
+    env = c['env_samples']
+    material_taps = max(c['tex_taps'] - env - misses, 0.0)      # 4-channel lookups that are not environment lookups
+    return {
+        # both queues: origin + direction in (32), hit out (16); 64 per wide node visited, 48 per triangle tested
+        'extend': 48 * c['rays'] + 64 * c['wide_nodes'] + 48 * c['wide_tris'],
+        # hit and direction in (32), shading triangle (112), material (128), texels; link + vertex arrays out (96); misses listed (4)
+        'resolve': 32 * c['path_rays'] + (112 + 128 + 96) * hits + tap4 * material_taps + tap1 * c['tex_taps_r'] * 0.5 + 4 * misses,
+        # link, vertex arrays and path record in (144); light sample: guide, column table, per-texel values (48); ray, path state, light out (112)
+        'vertex': (144 + 112) * hits + 48 * env,
+        # list entry and path record in (52), four environment texels (64), a new camera ray out (48)
+        'miss': (52 + 64 + 48) * misses,
+        # walk state in (80), uv words of the shading triangle (32), material (128), alpha/metallic texels; transmittance and state out (32), list entry (4)
+        'shadow': (80 + 32 + 128 + 36) * segments + tap1 * c['tex_taps_r'] * 0.5,
+        # list entry and whole record in (196), continuing path out (48)
+        'bsdf': (196 + 48) * hits,
+    }
+
+
+def self_launch(n):
+    """Starts this script n times under torch.distributed.run as a child process; returns its exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.startswith('{')]
+    for l in p.stdout.splitlines():
+        if not l.startswith('{'):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    return p.returncode if (lines or p.returncode) else 1
 
 
 def main():
@@ -54,9 +110,9 @@ def main():
     ap.add_argument('--soup-tris', type=int, default=10000000)
     ap.add_argument('--total-spp', type=int, default=0, help='samples per pixel of one step over ALL GPUs (strong scaling); 0 = --spp per GPU (weak scaling)')
     ap.add_argument('--no-cpu', action='store_true', help='skip the CPU oracle baseline')
-    ap.add_argument('--cpu-spp', type=int, default=12, help='frames the CPU oracle renders for the baseline (about 15 s on 16 cores)')
+    ap.add_argument('--cpu-spp', type=int, default=0, help='frames the CPU oracle renders for the baseline (0: 12 for the atrium workloads, 1 for the soup: about 15 s on 16 cores)')
     ap.add_argument('--mode', choices=['wavefront', 'single_kernel'], default='wavefront')
-    ap.add_argument('--pool', type=int, default=0, help='wavefront pool slots (0 = library default)')
+    ap.add_argument('--pool', type=int, default=0, help='samples in flight (0 = library default)')
     ap.add_argument('--chunk-frames', type=int, default=0, help='frames per staging chunk (0 = library default)')
     ap.add_argument('--backend', default='nccl', help='torch.distributed backend (nccl is RCCL; gloo lets several ranks rehearse on one GPU)')
     ap.add_argument('--device', type=int, default=-1, help='GPU to use (default: LOCAL_RANK)')
@@ -70,6 +126,10 @@ def main():
     ap.add_argument('--tune', type=str, default='', help='refill_lanes,leaf_vote,blocks_per_cu for the traversal kernel')
     args = ap.parse_args()
 
+    # launched plainly for several GPUs: become the launcher (a child process; this one has not touched the GPU)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
+
     import torch
     import torch.distributed as dist
     import ptamd
@@ -80,8 +140,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('launch with torch.distributed.run --nproc-per-node %d' % args.gpus)
+        raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs a GPU: the render path has no CPU fallback')
     device = local_rank if args.device < 0 else args.device
@@ -100,6 +159,7 @@ def main():
     # every rank generates the same seeded scene in its own directory
     util.SCRATCH = os.path.join(ROOT, 'tests', '_scratch', 'rank%d' % rank)
     bundle = None
+    soup_arrays = None
     if args.workload == 'soup':
         from ptamd import lib as ptlib
         tris, mats = scenes.soup(args.soup_tris, seed=2, extent=5000.0, edge=5.0)
@@ -115,6 +175,7 @@ def main():
         r.upload_scene(tris, mats, None, None, flavour=soup_flavour)
         r.upload_envmap(env4, cdf, env_total, P)
         n_tris = len(tris)
+        soup_arrays = (tris, mats, env4)
         workload_name = 'soup of %d random triangles (%s tree built on the GPU), 256x128 HDR envmap' % (n_tris, 'agglomerative' if args.tree == 'ploc' else 'radix')
     else:
         if args.workload == 'sunsky':
@@ -191,20 +252,33 @@ def main():
 
     for k in range(args.warmup):
         step(k, False)
-    r.stage_timing(True)
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + k, True)
     barrier()
     elapsed = time.perf_counter() - t0
-    extend_ms, extend_launches = r.stage_timing(False)
     image_mean = float(accum.mean().item()) / step_spp if rank == 0 else 0.0      # of the last step's reduced image (a checksum for N-GPU vs 1-GPU runs)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # untimed: the last timed step once more with HIP events around every stage kernel (on the launch streams), in the
+    # timed configuration (two lanes: a lane's kernels run beside the other's and are stretched by the sharing) and on
+    # one lane, where a step's kernel times add up
+    stage = {}
+    if args.mode == 'wavefront':
+        for tag in ('timed_config', 'one_lane'):
+            if tag == 'one_lane':
+                r.set_lanes(1)
+            r.stage_timing(True)
+            f0, f1 = frames_of(args.warmup + args.steps - 1)
+            r.render(P, f0, f1)
+            ms, iters = r.stage_times()
+            r.stage_timing(False)
+            stage[tag] = (ms, max(iters, 1))
+        r.set_lanes(args.lanes or 2)
     # untimed: count rays and tests of exactly the timed frames with the instrumented kernels, twice: the
     # reference-order binary walk (its box and triangle tests are the reference's own) and the production walk
     # over the wide nodes (the node visits and triangle tests the timed kernel really made)
@@ -221,7 +295,7 @@ def main():
         else:
             c['wide_nodes'], c['wide_tris'] = got['wide_nodes'], got['wide_tris']
     r.enable_counters(False)
-    keys = ['rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps', 'tex_taps_r', 'wide_nodes', 'wide_tris']
+    keys = ['rays', 'samples', 'box_tests', 'tri_tests', 'shade_vertices', 'env_samples', 'tex_taps', 'tex_taps_r', 'wide_nodes', 'wide_tris', 'path_rays']
     local = torch.tensor([float(c[k]) for k in keys], dtype=torch.float64, device='cuda')
     total = local.clone()
     if world > 1:
@@ -232,36 +306,65 @@ def main():
     result = None
     if rank == 0:
         mrays = tot['rays'] / elapsed / 1e6
+        node_b, tri_b = r.scene_bytes()
+        pm = {}
+        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+        if os.path.exists(pmc_path):
+            try:
+                with open(pmc_path) as f:
+                    pm = json.load(f).get(args.workload, {})
+                if pm.get('workload') != [W, H, spp, args.bounces]:
+                    pm = {}
+            except Exception:
+                pm = {}
+        pmk = pm.get('kernels', {})
+        kernels = []
         if args.mode == 'wavefront':
-            # dominant kernel: extend (closest hit for every pending ray of the pool), one launch per iteration
+            # dominant kernel: extend (closest hit for the pending ray of every record of both queues), one launch per iteration
             kname = 'wf_extend_kernel'
-            launches = max(extend_launches, 1)
-            kms = extend_ms / launches
-            # bytes the timed kernel's own walk asks the memory system for: per ray 32 in + 16 out (the slot
-            # arrays), 64 per wide node visited, 48 per triangle tested
-            own_per_launch = (48 * loc['rays'] + 64 * loc['wide_nodes'] + 48 * loc['wide_tris']) / launches
+            ms_timed, launches = stage['timed_config']
+            ms_one, launches_one = stage['one_lane']
+            kms = ms_timed['extend'] / launches
+            req = requested_bytes(loc, not args.fp32_textures)
+            # bytes the timed kernel's own walk asks the memory system for: per ray 32 in + 16 out (the queue
+            # arrays), 64 per wide node visited, 48 per triangle tested; over the counted steps / the launches of one step
+            own_per_launch = req['extend'] / args.steps / launches
             # the layout-independent accounting on the reference's binary walk
-            ref_per_launch = (40 * loc['rays'] + 32 * loc['box_tests'] + 48 * loc['tri_tests']) / launches
+            ref_per_launch = (40 * loc['rays'] + 32 * loc['box_tests'] + 48 * loc['tri_tests']) / args.steps / launches
             alg_per_launch = own_per_launch if loc['wide_nodes'] > 0 else ref_per_launch
+            for name in STAGES:
+                e = pmk.get(KERNEL_NAMES[name], {})
+                k_ms = ms_one[name] / launches_one
+                req_launch = req[name] / args.steps / launches_one
+                kernels.append({
+                    'kernel': KERNEL_NAMES[name],
+                    'ms_per_step': round(ms_one[name], 3), 'ms_per_step_timed_config': round(ms_timed[name], 3),
+                    'launches_per_step': int(launches_one), 'ms_per_launch': round(k_ms, 4),
+                    'requested_bytes_per_launch': int(req_launch),
+                    'requested_GBs': round(req_launch / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,
+                    'pmc_bytes_per_launch': e.get('pmc_bytes_per_launch'),
+                    'pmc_frac_of_hbm_peak': e.get('pmc_frac_of_hbm_peak'),
+                    'valu_busy': e.get('valu_busy'), 'valu_lanes_per_instruction': e.get('valu_lanes_per_instruction'),
+                    'valu_useful': (round(e['valu_busy'] * e['valu_lanes_per_instruction'], 3) if e.get('valu_busy') is not None else None),
+                    'wave_wait_share': e.get('wave_wait_share'), 'waves_per_simd': e.get('waves_per_simd'),
+                })
         else:
             kname = 'render_samples_kernel'
             launches = args.steps
             kms = float(np.mean(kernel_ms))
             alg_per_launch = ref_per_launch = own_per_launch = algorithmic_bytes(loc) / args.steps
         achieved = alg_per_launch / (kms * 1e-3) / 1e9
-        node_b, tri_b = r.scene_bytes()
-        traffic = None
-        issue = None
-        pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-        if os.path.exists(pmc_path):
-            try:
-                with open(pmc_path) as f:
-                    pm = json.load(f).get(args.workload, {})
-                if pm.get('workload') == [W, H, spp, args.bounces]:
-                    traffic = pm.get('hbm_bytes_per_launch')
-                    issue = pm.get('issue')
-            except Exception:
-                traffic = None
+        ext = pm.get('extend_timed_config') or {}
+        traffic = ext.get('pmc_bytes_per_launch')
+        traffic_frac = round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None
+        # What bounds the kernel, from the counters: memory when what reaches HBM is the larger share of its ceiling, else
+        # vector instruction issue (the scene is cache resident then and the requested bytes are a gather rate, not HBM use).
+        valu = ext.get('valu_busy')
+        if traffic_frac is None or valu is None:
+            bound = 'unmeasured (no counters committed for this workload and size; achieved is requested bytes over time)'
+        else:
+            bound = 'hbm' if traffic_frac >= valu else 'valu_issue'
+        ref_frac = ref_per_launch / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS
         result = {
             'metric': 'Mrays/s', 'value': round(mrays, 3), 'unit': 'Mrays/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -276,37 +379,45 @@ def main():
                                      ('samples: rank r renders frames [k*S + r*S/N, k*S + (r+1)*S/N) of step k, RCCL reduce to rank 0' if strong else
                                       'samples: rank r renders frames [(k*N+r)*spp, +spp), RCCL reduce to rank 0')),
                        'scene_bytes': {'nodes': node_b, 'triangles': tri_b}},
-            'roofline': {'bound': 'hbm', 'kernel': kname, 'launches': int(launches), 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5), 'traffic': traffic,
+            'roofline': {'bound': bound, 'kernel': kname, 'launches': int(launches), 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
+                         'frac_of': 'bytes the kernel requests (48 per ray + 64 per wide node visited + 48 per triangle tested) / launch time / HBM peak: a gather rate; most of it is served by L2 and Infinity Cache when the scene fits them',
+                         'traffic': traffic, 'hbm_traffic_frac': traffic_frac,
+                         'hbm_traffic_frac_of': 'PMC bytes that reached the memory side (FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json) / launch time / HBM peak',
                          'kernel_ms': round(kms, 4),
                          'algorithmic_bytes_per_launch': int(alg_per_launch),
                          'own_walk_per_ray': {'wide_nodes': round(loc['wide_nodes'] / max(loc['rays'], 1), 3), 'tri_tests': round(loc['wide_tris'] / max(loc['rays'], 1), 3),
-                                              'bytes': round(own_per_launch * launches / max(loc['rays'], 1), 1)},
+                                              'bytes': round(own_per_launch * launches * args.steps / max(loc['rays'], 1), 1)},
                          'reference_walk': {'box_tests_per_ray': round(loc['box_tests'] / max(loc['rays'], 1), 3), 'tri_tests_per_ray': round(loc['tri_tests'] / max(loc['rays'], 1), 3),
-                                            'bytes_per_launch': int(ref_per_launch), 'achieved': round(ref_per_launch / (kms * 1e-3) / 1e9, 2),
-                                            'frac': round(ref_per_launch / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
-                         'hbm_traffic_frac': (round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None),
-                         'issue': issue,
-                         'note': ('achieved = bytes the timed kernel asks the memory system for (48 per ray in the slot arrays + 64 per wide node it visits + 48 per triangle it tests, '
-                                  'counted on the production walk) / its mean launch time; reference_walk = the same with the layout-independent accounting on the reference\'s binary walk '
-                                  '(40 + 32 per box test + 48 per triangle test). '
-                                  + ('The %.0f MB the walk touches are served from L2 / Infinity Cache,' % ((node_b + tri_b) / 1e6) + ' so this fraction measures cache gather rate against the HBM peak, not HBM use: traffic (PMC) is what reaches memory, '
-                                     'and the kernel is bound by vector instruction issue (issue).' if args.workload != 'soup' else
-                                     'The %.1f GB of wide nodes and triangle records fit no cache: the node and triangle reads are random 64-byte accesses, of which the upper levels of the tree are served from the caches; see traffic and issue.' % ((node_b + tri_b) / 1e9))),
+                                            'bytes_per_launch': int(ref_per_launch), 'frac': round(ref_frac, 5),
+                                            'valid': ref_frac <= 1.0,
+                                            'note': 'the layout-independent accounting (40 + 32 per box test + 48 per triangle test of the reference\'s binary walk); above 1 it only says that the timed kernel does not do that work: its 4-wide walk visits a fifth as many nodes'},
+                         'issue': ({'valu_busy': valu, 'valu_lanes_per_instruction': ext.get('valu_lanes_per_instruction'), 'wave_wait_share': ext.get('wave_wait_share')} if valu is not None else None),
+                         'kernels': kernels,
+                         'kernels_note': 'ms_per_step: HIP events around every launch of one untimed step on one lane (the times add up to the step); ms_per_step_timed_config: the same in the timed configuration, where the kernels of two lanes share the GPU; requested bytes from the record layouts and the tallies of the instrumented run; pmc_*, valu_*, wave_wait_share, waves_per_simd from the committed rocprofv3 counter passes (profiles/pmc_traffic.json), null when none matches this workload and size',
                          'whole_path_algorithmic_GBs': round(algorithmic_bytes(loc) / (elapsed * 1e9), 2)},
         }
 
     # CPU baseline: the oracle on this host's cores, rank 0, single-GPU runs only, bounded sample
-    if rank == 0 and world == 1 and not args.no_cpu and bundle is not None:
+    if rank == 0 and world == 1 and not args.no_cpu:
         import orc
+        if bundle is None:
+            # the oracle walks the reference's tree: built on the host here, outside the timed region
+            tris, mats, env4 = soup_arrays
+            t_build = time.perf_counter()
+            bundle = util.Bundle(tris, mats, (), env4)
+            build_s = time.perf_counter() - t_build
+        else:
+            build_s = None
         S = bundle.oracle(P)
-        cpu_spp = args.cpu_spp
+        cpu_spp = args.cpu_spp or (1 if args.workload == 'soup' else 12)
         t1 = time.perf_counter()
         _, st = orc.render(S, P, 0, cpu_spp, args.bounces)
         dt = time.perf_counter() - t1
         result['cpu_baseline'] = {'value': round(st['rays'] / dt / 1e6, 3), 'unit': 'Mrays/s', 'cores': orc.max_threads(), 'kind': 'port',
                                   'samples_per_s': round(st['samples'] / dt, 1),
-                                  'sample': 'same scene and camera, %dx%d, frames [0,%d), %.1f s' % (W, H, cpu_spp, dt)}
+                                  'sample': 'same scene and camera, %dx%d, frames [0,%d), %.1f s%s' % (
+                                      W, H, cpu_spp, dt, '' if build_s is None else ' (reference tree built on the host in %.1f s, not timed)' % build_s)}
     if rank == 0:
         print(json.dumps(result))
     r.close()

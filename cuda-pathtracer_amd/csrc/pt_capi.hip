@@ -133,7 +133,7 @@ struct pt_ctx {
         size_t staging_bytes = 0;
         uint32_t* counters = nullptr;
         uint32_t* host_counters = nullptr;   // pinned
-        hipEvent_t st_ev[16] = {};
+        hipEvent_t st_ev[8 * kStageEvents] = {};    // per iteration of a batch: before extend, after each stage kernel
         hipEvent_t ready = nullptr;     // the last issued batch and its counter copy are done
         WfParams w{};
         int batch = 8;
@@ -168,6 +168,7 @@ struct pt_ctx {
     bool stage_timing = false;
     double extend_ms = 0.0;
     uint64_t extend_launches = 0;
+    double stage_ms[PT_STAGE_KERNELS] = {};     // extend, resolve, vertex, miss, shadow, bsdf
 };
 
 extern "C" {
@@ -997,7 +998,7 @@ static int fetch_counters(pt_ctx* c)
     DCounters h;
     HIP_TRY(hipMemcpyAsync(&h, c->d_ctr, sizeof(h), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    c->totals.rays += h.rays; c->totals.samples += h.samples;
+    c->totals.rays += h.rays; c->totals.samples += h.samples; c->totals.path_rays += h.path_rays;
     const bool wide_walk = c->counting == 2 && c->scene.wide && c->mode == PT_MODE_WAVEFRONT;
     if (wide_walk) { c->totals.wide_nodes += h.box_tests; c->totals.wide_tris += h.tri_tests; }
     else { c->totals.box_tests += h.box_tests; c->totals.tri_tests += h.tri_tests; }
@@ -1138,14 +1139,14 @@ static const int kMaxBatch = 8;
 
 static int lane_issue_batch(pt_ctx* c, pt_ctx::WfLane& L, const DCamera& cam, DCounters* ctr)
 {
-    if (c->stage_timing && !L.st_ev[0]) { for (int i = 0; i < 2 * kMaxBatch; i++) HIP_TRY(hipEventCreate(&L.st_ev[i])); }
+    if (c->stage_timing && !L.st_ev[0]) { for (int i = 0; i < kStageEvents * kMaxBatch; i++) HIP_TRY(hipEventCreate(&L.st_ev[i])); }
     if (L.all_started && !L.flushed) {
         // the global hand-out has run dry: start the ids workgroups still hold in their chunks, all at once
         launch_wf_flush_leftover(lane_feed_view(L), cam, ctr, L.stream);
         L.flushed = true;
     }
     for (int i = 0; i < L.batch; i++) {
-        launch_wf_iteration(lane_view(L), c->scene, cam, ctr, L.stream, c->stage_timing ? L.st_ev[2 * i] : nullptr, c->stage_timing ? L.st_ev[2 * i + 1] : nullptr);
+        launch_wf_iteration(lane_view(L), c->scene, cam, ctr, L.stream, c->stage_timing ? L.st_ev + kStageEvents * i : nullptr);
         L.parity ^= 1;
     }
     HIP_TRY(hipGetLastError());
@@ -1238,7 +1239,12 @@ static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1
                 if (L.finished) continue;
                 HIP_TRY(hipEventSynchronize(L.ready));
                 if (c->stage_timing) {
-                    for (int k = 0; k < L.batch; k++) { float ms = 0.f; if (hipEventElapsedTime(&ms, L.st_ev[2 * k], L.st_ev[2 * k + 1]) == hipSuccess) { c->extend_ms += ms; c->extend_launches++; } }
+                    for (int k = 0; k < L.batch; k++) {
+                        hipEvent_t* ev = L.st_ev + kStageEvents * k;
+                        for (int q = 0; q < PT_STAGE_KERNELS; q++) { float ms = 0.f; if (hipEventElapsedTime(&ms, ev[q], ev[q + 1]) == hipSuccess) c->stage_ms[q] += ms; }
+                        float ms = 0.f;
+                        if (hipEventElapsedTime(&ms, ev[0], ev[1]) == hipSuccess) { c->extend_ms += ms; c->extend_launches++; }
+                    }
                 }
                 const uint32_t* hc = L.host_counters;
                 // what the last iteration of the batch left in the queues it appended to
@@ -1287,6 +1293,15 @@ int pt_stage_timing(pt_ctx* c, int on, double* extend_ms_out, uint64_t* extend_l
     if (extend_launches_out) *extend_launches_out = c->extend_launches;
     c->stage_timing = on != 0;
     c->extend_ms = 0.0; c->extend_launches = 0;
+    for (double& v : c->stage_ms) v = 0.0;
+    return PT_OK;
+}
+
+int pt_stage_times(pt_ctx* c, double* ms_out, uint64_t* iterations_out)
+{
+    if (!c || !ms_out) { set_error("pt_stage_times: bad argument"); return PT_ERR_ARG; }
+    for (int q = 0; q < PT_STAGE_KERNELS; q++) ms_out[q] = c->stage_ms[q];
+    if (iterations_out) *iterations_out = c->extend_launches;
     return PT_OK;
 }
 

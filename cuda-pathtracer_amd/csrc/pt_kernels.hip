@@ -50,7 +50,7 @@ __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera ca
     if (x >= cam.W || y >= cam.H) return;
     size_t pix = (size_t)(x + y * cam.W) * 3;
     F3 acc = f3(accum[pix], accum[pix + 1], accum[pix + 2]);
-    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
     for (int frame = frame_begin; frame < frame_end; frame++) {
         Path P;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera ca
         if (!cam.is_rendering) {
             // preview: pathtracer.cu:504-525
             Hit h = closest_hit<64, kLdsDepth, COUNT>(S, P.o, P.d, threadIdx.x, tl.box, tl.tri);
-            if (COUNT) tl.rays++;
+            if (COUNT) { tl.rays++; tl.path_rays++; }
             Surf info;
             resolve_hit<COUNT>(S, h, P.d, info, tl.taps, tl.taps_r);
             if (info.hit) {
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera ca
                 F3 ro = shadow ? P.so : P.o;
                 F3 rd = shadow ? P.sd : P.d;
                 Hit h = closest_hit<64, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
-                if (COUNT) tl.rays++;
+                if (COUNT) { tl.rays++; if (!shadow) tl.path_rays++; }
                 Surf info;
                 resolve_hit<COUNT>(S, h, rd, info, tl.taps, tl.taps_r);
                 if (shadow) on_shadow_hit<COUNT>(S, cam, P, info, tl);
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(64) void render_samples_kernel(DScene S, DCamera ca
     accum[pix] = acc.x; accum[pix + 1] = acc.y; accum[pix + 2] = acc.z;
     if (COUNT) {
         atomicAdd(&ctr->rays, (unsigned long long)tl.rays);
+        atomicAdd(&ctr->path_rays, (unsigned long long)tl.path_rays);
         atomicAdd(&ctr->samples, (unsigned long long)nsamples);
         atomicAdd(&ctr->box_tests, (unsigned long long)tl.box);
         atomicAdd(&ctr->tri_tests, (unsigned long long)tl.tri);

@@ -9,7 +9,8 @@ void launch_render_samples(const DScene& S, const DCamera& cam, int frame_begin,
 void launch_resolve_display(const float* accum_dev, int n_pixels, int n_frames, uint8_t* rgba_dev, hipStream_t stream);
 void launch_post_process(const uint8_t* in_dev, int n_pixels, float exposure, const float* mult3, float saturation, float gamma, uint8_t* out_dev, hipStream_t stream);
 void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, hipStream_t s);
-void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t ext0, hipEvent_t ext1);
+constexpr int kStageEvents = 7;
+void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t* ev);
 void launch_wf_flush_leftover(const WfParams& w, const DCamera& cam, DCounters* ctr, hipStream_t s);
 void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int max_paths, DCounters* ctr, hipStream_t s);
 void launch_wf_accumulate(const WfParams& w, const DCamera& cam, float* accum_dev, int first, int count, hipStream_t s);

@@ -115,7 +115,7 @@ struct DCamera {
 };
 
 struct DCounters {
-    unsigned long long rays, samples, box_tests, tri_tests, shade_vertices, env_samples, tex_taps, tex_taps_r;
+    unsigned long long rays, samples, box_tests, tri_tests, shade_vertices, env_samples, tex_taps, tex_taps_r, path_rays;
 };
 
 // ---------------------------------------------------------------- wavefront queues

@@ -52,7 +52,7 @@ PT_DEV int lobe_class(const Mat& m)
     return ((1.0f - m.metal) * (1.0f - m.strans) > 0.f ? 1 : 0) | (m.metal > 0.f ? 2 : 0) | ((1.0f - m.metal) * m.strans > 0.f ? 4 : 0) | (m.coat > 0.f ? 8 : 0);
 }
 
-struct Tally { uint32_t rays, box, tri, verts, envs, taps, taps_r; };
+struct Tally { uint32_t rays, box, tri, verts, envs, taps, taps_r, path_rays; };
 
 // pathtracer.cu:559-579 + 527: pixel seed, jitter, camera ray, optional thin lens, channel pick.
 PT_DEV void begin_sample(Path& P, const DCamera& cam, int x, int y, int frame)

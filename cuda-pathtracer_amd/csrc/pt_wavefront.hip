@@ -283,9 +283,10 @@ PT_DEV void flush_tally(DCounters* ctr, const Tally& tl, uint32_t nsamples)
     // one atomic per counter per wave
     auto wave_sum = [](uint32_t v) { for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_down((int)v, o, 64); return v; };
     uint32_t r = wave_sum(tl.rays), b = wave_sum(tl.box), t = wave_sum(tl.tri), v = wave_sum(tl.verts), e = wave_sum(tl.envs);
-    uint32_t x = wave_sum(tl.taps), y = wave_sum(tl.taps_r), s = wave_sum(nsamples);
+    uint32_t x = wave_sum(tl.taps), y = wave_sum(tl.taps_r), s = wave_sum(nsamples), p = wave_sum(tl.path_rays);
     if ((threadIdx.x & 63u) == 0) {
         if (r) atomicAdd(&ctr->rays, (unsigned long long)r);
+        if (p) atomicAdd(&ctr->path_rays, (unsigned long long)p);
         if (b) atomicAdd(&ctr->box_tests, (unsigned long long)b);
         if (t) atomicAdd(&ctr->tri_tests, (unsigned long long)t);
         if (v) atomicAdd(&ctr->shade_vertices, (unsigned long long)v);
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
     reserve<1>(a);
     if (have) store_path(w.Pn, a.pos[0], P, s);
     if (blockIdx.x == 0 && threadIdx.x == 0) w.counters[WF_CTR_NEXT_SAMPLE] = n_start;
-    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
 
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     const uint32_t n_chunks = w.counters[WF_CTR_RAY_CHUNKS], n_pchunks = w.counters[WF_CTR_RAY_P_CHUNKS];
     const uint32_t n_path = w.counters[WF_CTR_N_P], n_shadow = w.counters[WF_CTR_N_S];
     const uint32_t n_small = n_chunks < PT_TAIL_FACTOR * gridDim.x ? n_chunks : PT_TAIL_FACTOR * gridDim.x, n_big = n_chunks - n_small;
-    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
 #if PT_STAMPS
     unsigned long long st_iters = 0, st_lanes = 0, st_leafphases = 0, st_refills = 0, st_leaflanes = 0, st_idle = 0, st_tail = 0, st_tail_idle = 0, st_tail_desc = 0, st_tail_t0 = 0, st_t0 = __builtin_amdgcn_s_memtime();
     uint32_t st_age = 0; unsigned long long st_h64 = 0, st_h128 = 0, st_h256 = 0, st_h512 = 0, st_max = 0;
@@ -623,7 +624,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
             st_age = 0;
 #endif
             has_ray = true;
-            if (COUNT) tl.rays++;
+            if (COUNT) { tl.rays++; if (!chunk_shadow) tl.path_rays++; }
             cur = PT_TRAV_EMPTY;
             if (finite3(o) && finite3(d)) {
                 // the quantized boxes carry two cells of padding (the root box 0.1 units): the hardware reciprocal's
@@ -679,7 +680,7 @@ __global__ __launch_bounds__(kBlock) void wf_resolve_kernel(WfParams w, DScene S
 {
     const uint32_t n_in = w.counters[WF_CTR_N_P];
     const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
-    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
         const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_PATH);
         if (seg >= n_seg) break;                    // uniform over the workgroup
@@ -728,7 +729,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTE
 {
     const uint32_t n_in = w.counters[WF_CTR_TAIL_S];      // the records the resolve stage allocated; nothing else has appended yet
     const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
-    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
     for (;;) {
         const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_VERTEX);
@@ -794,7 +795,7 @@ __global__ __launch_bounds__(kBlock) void wf_miss_kernel(WfParams w, DScene S, D
 {
     const uint32_t n_in = w.counters[WF_CTR_TAIL_M];
     const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
-    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
     for (;;) {
         const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_MISS);
@@ -834,7 +835,7 @@ __global__ __launch_bounds__(kBlock) void wf_shadow_kernel(WfParams w, DScene S,
     const uint32_t n_in = w.counters[WF_CTR_N_S];
     const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
     const int lane = (int)(threadIdx.x & 63u);
-    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
         if (threadIdx.x < kKinds) s_kind[threadIdx.x] = 0u;
         const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_SHADOW);      // (its barriers also publish the cleared counts)
@@ -931,7 +932,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_BSDF_
 {
     const uint32_t n_in = w.counters[WF_CTR_TAIL_B];
     const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
-    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
     for (;;) {
         const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_BSDF);
@@ -989,7 +990,7 @@ __global__ __launch_bounds__(kBlock) void wf_flush_leftover_kernel(WfParams w, D
     a.want[0] = have; a.tail[0] = w.counters + WF_CTR_TAIL_P;
     reserve<1>(a);
     if (have) store_path(w.Pn, a.pos[0], P, s);
-    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
 
@@ -1005,7 +1006,7 @@ __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, 
     if (blockIdx.x * (uint32_t)kBlock >= n_paths) return;
     const uint32_t q = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
     bool have = q < n_paths;             // lanes past the end stay for the wave-wide tally
-    Tally tl = {0, 0, 0, 0, 0, 0, 0};
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     Path P;
     SampleId id = {0, 0, 0, 0u, 0u};
     P.state = ST_DONE;
@@ -1026,7 +1027,7 @@ __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, 
             Hit h;
             if (WIDE) h = closest_hit_wide<kBlock, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
             else h = closest_hit<kBlock, kLdsDepth, COUNT>(S, ro, rd, threadIdx.x, tl.box, tl.tri);
-            if (COUNT) tl.rays++;
+            if (COUNT) { tl.rays++; if (!shadow) tl.path_rays++; }
             Surf info;
             resolve_hit<COUNT>(S, h, rd, info, tl.taps, tl.taps_r, shadow);
             if (shadow) on_shadow_hit<COUNT>(S, cam, P, info, tl);
@@ -1161,11 +1162,12 @@ void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, h
 }
 
 // One iteration: the queues the last iteration appended to (w.Pc, w.Sc) are traced and consumed, w.Pn and w.Sn filled.
-void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t ext0, hipEvent_t ext1)
+// ev: null, or kStageEvents events recorded before the extend launch and after each of the six stage kernels
+void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t* ev)
 {
     dim3 block(kBlock), stage(w.stage_blocks);
     hipLaunchKernelGGL(wf_plan_kernel, dim3(1), block, 0, s, w.counters, (const uint32_t*)w.wg_chunk, w.stage_blocks, w.n_samples);
-    if (ext0) (void)hipEventRecord(ext0, s);
+    if (ev) (void)hipEventRecord(ev[0], s);
     // persistent waves: enough workgroups to fill every CU, each pulls rays until both queues are drained
     int ext_blocks = (w.n_slots + kBlock - 1) / kBlock;
     if (ext_blocks > w.extend_blocks) ext_blocks = w.extend_blocks;
@@ -1173,20 +1175,16 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
     else if (ctr) hipLaunchKernelGGL((wf_extend_kernel<true, false>), dim3(ext_blocks), block, 0, s, w, S, ctr);
     else if (S.wide) hipLaunchKernelGGL((wf_extend_kernel<false, true>), dim3(ext_blocks), block, 0, s, w, S, ctr);
     else hipLaunchKernelGGL((wf_extend_kernel<false, false>), dim3(ext_blocks), block, 0, s, w, S, ctr);
-    if (ext1) (void)hipEventRecord(ext1, s);
-    if (ctr) {
-        hipLaunchKernelGGL(wf_resolve_kernel<true>, stage, block, 0, s, w, S, ctr);
-        hipLaunchKernelGGL(wf_vertex_kernel<true>, stage, block, 0, s, w, S, cam, ctr);      // before anything else appends to the next shadow queue
-        hipLaunchKernelGGL(wf_miss_kernel<true>, stage, block, 0, s, w, S, cam, ctr);
-        hipLaunchKernelGGL(wf_shadow_kernel<true>, stage, block, 0, s, w, S, cam, ctr);
-        hipLaunchKernelGGL(wf_bsdf_kernel<true>, stage, block, 0, s, w, S, cam, ctr);
-    } else {
-        hipLaunchKernelGGL(wf_resolve_kernel<false>, stage, block, 0, s, w, S, ctr);
-        hipLaunchKernelGGL(wf_vertex_kernel<false>, stage, block, 0, s, w, S, cam, ctr);      // before anything else appends to the next shadow queue
-        hipLaunchKernelGGL(wf_miss_kernel<false>, stage, block, 0, s, w, S, cam, ctr);
-        hipLaunchKernelGGL(wf_shadow_kernel<false>, stage, block, 0, s, w, S, cam, ctr);
-        hipLaunchKernelGGL(wf_bsdf_kernel<false>, stage, block, 0, s, w, S, cam, ctr);
-    }
+    if (ev) (void)hipEventRecord(ev[1], s);
+#define PT_STAGE(kernel, k, ...) do { \
+        if (ctr) hipLaunchKernelGGL(kernel<true>, stage, block, 0, s, __VA_ARGS__); else hipLaunchKernelGGL(kernel<false>, stage, block, 0, s, __VA_ARGS__); \
+        if (ev) (void)hipEventRecord(ev[k], s); } while (0)
+    PT_STAGE(wf_resolve_kernel, 2, w, S, ctr);
+    PT_STAGE(wf_vertex_kernel, 3, w, S, cam, ctr);      // before anything else appends to the next shadow queue
+    PT_STAGE(wf_miss_kernel, 4, w, S, cam, ctr);
+    PT_STAGE(wf_shadow_kernel, 5, w, S, cam, ctr);
+    PT_STAGE(wf_bsdf_kernel, 6, w, S, cam, ctr);
+#undef PT_STAGE
 }
 
 // w.Pn: the path queue the next iteration will read (its tail word is still open)

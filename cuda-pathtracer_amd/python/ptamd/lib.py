@@ -25,7 +25,7 @@ EXPORTS = [
     'pt_upload_materials', 'pt_upload_bvh', 'pt_build_bvh', 'pt_render_frame', 'pt_render_frame_async', 'pt_frame_fetch', 'pt_set_frame_lookahead', 'pt_upload_texture', 'pt_upload_envmap',
     'pt_set_sky_mode', 'pt_set_env_guides', 'pt_set_max_bounces', 'pt_set_mode', 'pt_set_pool', 'pt_set_drain', 'pt_wavefront_stats', 'pt_set_lanes', 'pt_set_extend_tuning', 'pt_set_node_width', 'pt_render_headless', 'pt_group_create', 'pt_group_frames', 'pt_group_render', 'pt_group_destroy', 'pt_sync', 'pt_read_accum', 'pt_write_accum',
     'pt_accum_device_ptr', 'pt_bind_accum', 'pt_resolve_display', 'pt_save_png', 'pt_resolve_display_post', 'pt_save_pfm', 'pt_save_exr', 'pt_load_pfm', 'pt_trace_closest', 'pt_trace_closest_dev',
-    'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_trace_closest_noalloc_dev', 'pt_debug_words', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_scene_bytes',
+    'pt_trace_closest_counted', 'pt_trace_closest_fast', 'pt_trace_closest_fast_dev', 'pt_trace_closest_noalloc_dev', 'pt_debug_words', 'pt_get_counters', 'pt_reset_counters', 'pt_enable_counters', 'pt_stage_timing', 'pt_stage_times', 'pt_scene_bytes',
     'pt_detmath_probe', 'pt_bsdf_probe', 'pt_unorm8_probe', 'pt_set_texture_packing', 'pt_read_obj', 'pt_read_obj_general', 'pt_host_scene_free', 'pt_host_scene_counts', 'pt_host_scene_triangles',
     'pt_host_scene_tri_idx', 'pt_host_scene_materials', 'pt_host_scene_material_name', 'pt_host_scene_texture_info',
     'pt_host_build_bvh', 'pt_load_hdr', 'pt_load_texture_png', 'pt_load_texture_image', 'pt_build_env_cdf', 'pt_free', 'pt_camera_basis',
@@ -380,6 +380,12 @@ class Renderer:
         ms, n = C.c_double(), C.c_uint64()
         check(lib().pt_stage_timing(self.h, C.c_int(1 if on else 0), C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def stage_times(self):
+        """({kernel: ms}, iterations) accumulated since stage timing was switched on (extend, resolve, vertex, miss, shadow, bsdf)."""
+        ms, n = (C.c_double * 6)(), C.c_uint64()
+        check(lib().pt_stage_times(self.h, ms, C.byref(n)))
+        return dict(zip(('extend', 'resolve', 'vertex', 'miss', 'shadow', 'bsdf'), list(ms))), n.value
 
     def scene_bytes(self):
         a, b = C.c_uint64(), C.c_uint64()

@@ -50,7 +50,7 @@ assert C.sizeof(Params) == 152
 class Counters(C.Structure):
     _fields_ = [('rays', C.c_uint64), ('samples', C.c_uint64), ('box_tests', C.c_uint64), ('tri_tests', C.c_uint64),
                 ('shade_vertices', C.c_uint64), ('env_samples', C.c_uint64), ('tex_taps', C.c_uint64), ('tex_taps_r', C.c_uint64),
-                ('wide_nodes', C.c_uint64), ('wide_tris', C.c_uint64), ('last_ms', C.c_double)]
+                ('wide_nodes', C.c_uint64), ('wide_tris', C.c_uint64), ('path_rays', C.c_uint64), ('last_ms', C.c_double)]
 
 
 def default_params(width, height):

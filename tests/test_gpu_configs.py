@@ -176,6 +176,39 @@ def test_4k_render_properties():
         assert np.array_equal(bits(acc), bits(late[y, x])), (x, y, 'late')
 
 
+# ------------------------------------------------------------------ sun/sky, glossy metal and glass, 1080p
+def test_sun_sky_glossy_glass_full_size_properties():
+    """The fifth benchmark configuration at its full size: the 262k-triangle atrium with 30 % glossy metal and 20 %
+    glass materials under the sun/sky model, bounce cap 16, 1920x1080. Wavefront == single kernel, frame ranges
+    compose, and a sparse sample of pixels equals the oracle (vertices reach the bsdf stage without a visibility walk
+    here, and glass paths toggle the medium flag)."""
+    b = util.atrium(glossy=0.3, glass=0.2, sky_mode=1)
+    W, H = 1920, 1080
+    P = scenes.atrium_params(ptamd.default_params(W, H))
+    r = b.renderer(P)
+    r.set_max_bounces(16)
+    r.render(P, 0, 3)
+    wave = r.read_accum()
+    r.clear_accum()
+    r.render(P, 0, 1)
+    r.render(P, 1, 3)
+    assert np.array_equal(bits(r.read_accum()), bits(wave))
+    r.set_mode(1)
+    r.clear_accum()
+    r.render(P, 0, 3)
+    assert np.array_equal(bits(r.read_accum()), bits(wave))
+    r.close()
+    assert np.isfinite(wave).all() and wave.min() >= 0 and wave.mean() > 0.01
+    S = b.oracle(P)
+    rng = np.random.default_rng(28)
+    for x, y in zip(rng.integers(0, W, 100), rng.integers(0, H, 100)):
+        acc = np.zeros(3, np.float32)
+        for f in range(3):
+            rgb, _ = orc.pixel_sample(S, P, int(x), int(y), f, 16)
+            acc = acc + rgb
+        assert np.array_equal(bits(acc), bits(wave[y, x])), (x, y)
+
+
 # ------------------------------------------------------------------ 10 million triangles
 def test_ten_million_triangle_soup():
     """The large-mesh configuration: 10 M random triangles (2.4 GB of nodes and triangle records, beyond every

@@ -51,6 +51,20 @@ def test_noalloc_closest_hits_equal_the_allocating_entry_point():
         assert (got['tri'][:n] != 0xFFFFFFFF).sum() > 0 or n == 1
         # nothing past the batch is written
         assert np.all(np.frombuffer(got.tobytes(), np.uint8)[n * HIT_DTYPE.itemsize:] == 0xAB), n
+    # the property the entry point is named for: on a warmed context a call leaves the device's free memory where it
+    # was (a hipMalloc anywhere on the way, even one freed again later by a caching allocator, would show here or in
+    # the driver's own count below)
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info()
+    reserved_before = torch.cuda.memory_reserved()
+    for n in (n_max, 4097, n_max):
+        r.trace_closest_noalloc_dev(d_rays.data_ptr(), n, got_buf.data_ptr())
+    r.sync()
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info()
+    assert free_after == free_before, (free_before, free_after)
+    assert torch.cuda.memory_reserved() == reserved_before
+    # (the allocating entry point, by contrast, grows the library's pool when the batch does)
     # a second context on the same GPU shares the block; calls in sequence do not disturb each other
     r2 = b.renderer(P)
     r2.trace_closest_noalloc_dev(d_rays.data_ptr(), 5000, got_buf.data_ptr())
