@@ -1248,7 +1248,8 @@ static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1
                 }
                 const uint32_t* hc = L.host_counters;
                 // what the last iteration of the batch left in the queues it appended to
-                const uint64_t live = (uint64_t)hc[WF_CTR_TAIL_P] + (uint64_t)hc[WF_CTR_TAIL_S];
+                // (without light samples the shadow queue holds only records that went through the bsdf stage already)
+                const uint64_t live = (uint64_t)hc[WF_CTR_TAIL_P] + (c->scene.sky_mode == PT_SKY_SUNSKY ? 0u : (uint64_t)hc[WF_CTR_TAIL_S]);
                 // Nothing more can start once the global hand-out had run dry before the batch was issued and the
                 // batch began by starting the ids the workgroups still held.
                 const bool settled = L.flushed;

@@ -331,7 +331,9 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
 // ---------------------------------------------------------------- plan
 // Runs before every extend launch (one small workgroup): what the stages of the last iteration appended becomes
 // the current queues, and the per-iteration counters start over.
-__global__ __launch_bounds__(kBlock) void wf_plan_kernel(uint32_t* __restrict__ counters, const uint32_t* __restrict__ wg_chunk, int stage_blocks, uint32_t n_samples)
+// no_walks: the scene draws no light samples (sun/sky mode), so every record of the shadow queue went through the bsdf
+// stage in the iteration that wrote it and none waits for a ray: the queue is dropped instead of being scanned.
+__global__ __launch_bounds__(kBlock) void wf_plan_kernel(uint32_t* __restrict__ counters, const uint32_t* __restrict__ wg_chunk, int stage_blocks, uint32_t n_samples, int no_walks)
 {
     __shared__ uint32_t s_left[kBlock / 64];
     const int tid = (int)threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -347,7 +349,7 @@ __global__ __launch_bounds__(kBlock) void wf_plan_kernel(uint32_t* __restrict__ 
     if (tid == 0) {
         uint32_t leftover = 0;
         for (int j = 0; j < kBlock / 64; j++) leftover += s_left[j];
-        const uint32_t nP = counters[WF_CTR_TAIL_P], nS = counters[WF_CTR_TAIL_S];
+        const uint32_t nP = counters[WF_CTR_TAIL_P], nS = no_walks ? 0u : counters[WF_CTR_TAIL_S];
         counters[WF_CTR_N_P] = nP; counters[WF_CTR_N_S] = nS;
         counters[WF_CTR_TAIL_P] = 0; counters[WF_CTR_TAIL_S] = 0; counters[WF_CTR_TAIL_B] = 0; counters[WF_CTR_TAIL_M] = 0;
         counters[WF_CTR_RAY_NEXT] = 0;
@@ -724,7 +726,9 @@ __global__ __launch_bounds__(kBlock) void wf_resolve_kernel(WfParams w, DScene S
 #ifndef PT_VERTEX_WAVES
 #define PT_VERTEX_WAVES 4
 #endif
-template <bool COUNT>
+// DIRECT: for scenes that draw no light samples (sun/sky mode). The vertex has no visibility walk to wait for, so
+// its bsdf stage (after_light) runs here, on the state in registers, instead of going through a shadow-queue record.
+template <bool COUNT, bool DIRECT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTEX_WAVES))) void wf_vertex_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
     const uint32_t n_in = w.counters[WF_CTR_TAIL_S];      // the records the resolve stage allocated; nothing else has appended yet
@@ -759,6 +763,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTE
                 m.sigA = f3(M.sigA[0], M.sigA[1], M.sigA[2]); m.sigS = f3(M.sigS[0], M.sigS[1], M.sigS[2]);
             }
             on_path_vertex<COUNT>(S, cam, P, info, tl);
+            if (DIRECT && P.state == ST_AFTER) after_light<COUNT>(S, cam, P, tl);
             finished = P.state == ST_DONE;
         }
         finish_and_regenerate<COUNT>(w, cam, P, sample, id, finished, nsamples);
@@ -778,7 +783,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTE
             store_core(w.Sn.c0, w.Sn.c1, w.Sn.c2, j, P, sample);
             w.Sn.d0[j] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
             w.Sn.d1[j] = make_float4(P.env_color.x, P.env_color.y, P.env_color.z, 0.f);
-        } else if (have) {
+        } else if (have && !DIRECT) {
             w.Sn.sd[j] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));       // a dead record: no ray, no sample
         }
         if (ap.want[1]) w.bsdf_list[ap.pos[1]] = j | 0x80000000u;
@@ -1166,7 +1171,7 @@ void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, h
 void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam, DCounters* ctr, hipStream_t s, hipEvent_t* ev)
 {
     dim3 block(kBlock), stage(w.stage_blocks);
-    hipLaunchKernelGGL(wf_plan_kernel, dim3(1), block, 0, s, w.counters, (const uint32_t*)w.wg_chunk, w.stage_blocks, w.n_samples);
+    hipLaunchKernelGGL(wf_plan_kernel, dim3(1), block, 0, s, w.counters, (const uint32_t*)w.wg_chunk, w.stage_blocks, w.n_samples, S.sky_mode == PT_SKY_SUNSKY ? 1 : 0);
     if (ev) (void)hipEventRecord(ev[0], s);
     // persistent waves: enough workgroups to fill every CU, each pulls rays until both queues are drained
     int ext_blocks = (w.n_slots + kBlock - 1) / kBlock;
@@ -1180,7 +1185,13 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
         if (ctr) hipLaunchKernelGGL(kernel<true>, stage, block, 0, s, __VA_ARGS__); else hipLaunchKernelGGL(kernel<false>, stage, block, 0, s, __VA_ARGS__); \
         if (ev) (void)hipEventRecord(ev[k], s); } while (0)
     PT_STAGE(wf_resolve_kernel, 2, w, S, ctr);
-    PT_STAGE(wf_vertex_kernel, 3, w, S, cam, ctr);      // before anything else appends to the next shadow queue
+    // (before anything else appends to the next shadow queue)
+    if (S.sky_mode == PT_SKY_SUNSKY) {
+        if (ctr) hipLaunchKernelGGL((wf_vertex_kernel<true, true>), stage, block, 0, s, w, S, cam, ctr); else hipLaunchKernelGGL((wf_vertex_kernel<false, true>), stage, block, 0, s, w, S, cam, ctr);
+    } else {
+        if (ctr) hipLaunchKernelGGL((wf_vertex_kernel<true, false>), stage, block, 0, s, w, S, cam, ctr); else hipLaunchKernelGGL((wf_vertex_kernel<false, false>), stage, block, 0, s, w, S, cam, ctr);
+    }
+    if (ev) (void)hipEventRecord(ev[3], s);
     PT_STAGE(wf_miss_kernel, 4, w, S, cam, ctr);
     PT_STAGE(wf_shadow_kernel, 5, w, S, cam, ctr);
     PT_STAGE(wf_bsdf_kernel, 6, w, S, cam, ctr);
@@ -1197,7 +1208,7 @@ void launch_wf_flush_leftover(const WfParams& w, const DCamera& cam, DCounters* 
 // w as for the iteration that would come next; max_paths: an upper bound of the records in both queues
 void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int max_paths, DCounters* ctr, hipStream_t s)
 {
-    hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(kBlock), 0, s, w.counters, (const uint32_t*)w.wg_chunk, w.stage_blocks, w.n_samples);
+    hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(kBlock), 0, s, w.counters, (const uint32_t*)w.wg_chunk, w.stage_blocks, w.n_samples, S.sky_mode == PT_SKY_SUNSKY ? 1 : 0);
     int max_blocks = (max_paths + kBlock - 1) / kBlock;
     if (max_blocks < 1) max_blocks = 1;
     if (ctr && w.count_wide && S.wide) hipLaunchKernelGGL((wf_drain_kernel<true, true>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, ctr);
