@@ -1872,7 +1872,13 @@ struct Rccl {
     bool load()
     {
         if (handle) return true;
-        for (const char* name : {"librccl.so.1", "librccl.so"}) { handle = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (handle) break; }
+        // PTAMD_RCCL_LIBRARY names the library to use instead (an installation whose RCCL lives elsewhere; the tests'
+        // stand-in that sums through host memory on a one-GPU machine). Otherwise the name is looked up as the loader
+        // does: a process that already holds an RCCL (torch brings its own, soname librccl.so.1) gets that one, so the
+        // group and torch.distributed share one copy and one HIP runtime.
+        const char* named = getenv("PTAMD_RCCL_LIBRARY");
+        if (named && *named) handle = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+        else for (const char* name : {"librccl.so.1", "librccl.so"}) { handle = dlopen(name, RTLD_NOW | RTLD_LOCAL); if (handle) break; }
         if (!handle) { set_error("pt_group_create: cannot load RCCL (%s)", dlerror()); return false; }
         auto sym = [&](const char* n) { void* p = dlsym(handle, n); if (!p) set_error("pt_group_create: RCCL lacks %s", n); return p; };
         CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
@@ -1889,6 +1895,7 @@ Rccl g_rccl;
 
 struct pt_group {
     std::vector<pt_ctx*> ctx;
+    std::vector<int> device;          // of each context, kept here so that the group can be destroyed after its contexts
     std::vector<ncclComm_t> comm;     // empty for a group of one
 };
 
@@ -1909,11 +1916,17 @@ int pt_group_create(pt_ctx** ctxs, int n, pt_group** out)
     for (int i = 0; i < n; i++) {
         if (!ctxs[i] || !ctxs[i]->accum) { set_error("pt_group_create: context %d is not initialised", i); return PT_ERR_STATE; }
         if (ctxs[i]->W != ctxs[0]->W || ctxs[i]->H != ctxs[0]->H) { set_error("pt_group_create: context %d has another image size", i); return PT_ERR_ARG; }
-        for (int j = 0; j < i; j++) if (ctxs[j]->device == ctxs[i]->device) { set_error("pt_group_create: contexts %d and %d share GPU %d; a group takes one context per GPU", j, i, ctxs[i]->device); return PT_ERR_ARG; }
+        // (PTAMD_GROUP_SHARED_GPU=1 lifts this for rehearsals on a one-GPU machine with a stand-in for RCCL; RCCL itself
+        // refuses two ranks on one device)
+        const char* shared = getenv("PTAMD_GROUP_SHARED_GPU");
+        if (!(shared && shared[0] == '1'))
+            for (int j = 0; j < i; j++) if (ctxs[j]->device == ctxs[i]->device) { set_error("pt_group_create: contexts %d and %d share GPU %d; a group takes one context per GPU", j, i, ctxs[i]->device); return PT_ERR_ARG; }
+        for (int j = 0; j < i; j++) if (ctxs[j] == ctxs[i]) { set_error("pt_group_create: context %d is listed twice", i); return PT_ERR_ARG; }
     }
     pt_group* g = new (std::nothrow) pt_group();
     if (!g) { set_error("out of memory"); return PT_ERR_NOMEM; }
     g->ctx.assign(ctxs, ctxs + n);
+    for (int i = 0; i < n; i++) g->device.push_back(ctxs[i]->device);
     if (n > 1) {
         if (!g_rccl.load()) { delete g; return PT_ERR_STATE; }
         std::vector<int> devs(n);
@@ -1929,7 +1942,7 @@ int pt_group_create(pt_ctx** ctxs, int n, pt_group** out)
 void pt_group_destroy(pt_group* g)
 {
     if (!g) return;
-    for (size_t i = 0; i < g->comm.size(); i++) { (void)hipSetDevice(g->ctx[i]->device); (void)g_rccl.CommDestroy(g->comm[i]); }
+    for (size_t i = 0; i < g->comm.size(); i++) { (void)hipSetDevice(g->device[i]); (void)g_rccl.CommDestroy(g->comm[i]); }
     delete g;
 }
 

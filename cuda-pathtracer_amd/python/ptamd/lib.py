@@ -5,6 +5,7 @@ There is no Python or CPU fallback; a missing library or a missing GPU raises.
 """
 import ctypes as C
 import os
+import sys
 import numpy as np
 
 from .types import TRI_DTYPE, NODE_DTYPE, MAT_DTYPE, RAY_DTYPE, HIT_DTYPE, Params, Counters, Float3
@@ -43,6 +44,15 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise PtError('%s is missing: build it with `make -C cuda-pathtracer_amd` (or __graft_entry__.build())' % LIB_PATH)
+        # torch ships its own copy of the HIP runtime (soname libamdhip64.so.7, asked for as libamdhip64.so). Loaded first,
+        # that copy also satisfies this library's libamdhip64.so.7 and the process holds one runtime; loaded after this
+        # library it becomes a second runtime beside /opt/rocm's and torch then finds no GPU. So, where torch is installed
+        # and not yet imported, it is imported here (PTAMD_NO_TORCH_FIRST=1 skips that).
+        if 'torch' not in sys.modules and os.environ.get('PTAMD_NO_TORCH_FIRST') != '1':
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         L = C.CDLL(LIB_PATH)
         L.pt_last_error.restype = C.c_char_p
         L.pt_host_scene_triangles.restype = C.c_void_p

@@ -797,6 +797,58 @@ def test_group_of_one_gpu_and_group_errors():
     r.close(); r2.close()
 
 
+def test_group_of_two_ranks_through_a_stand_in_for_rccl():
+    """The n > 1 branch of pt_group_render on a one-GPU machine: two contexts on GPU 0 (PTAMD_GROUP_SHARED_GPU) and
+    tests/fake_rccl.c in place of RCCL (PTAMD_RCCL_LIBRARY), in a process of its own because the library reads both
+    once. Exercised: ncclCommInitAll over the group's devices, one host thread per context, the frame split, the
+    clearing of the other ranks' accumulators, the grouped in-place reduce onto context 0 behind each context's
+    render, and destruction after the contexts. The sum is fp32 rank 0 + rank 1, so it equals the two parts added
+    in numpy bit for bit, and the one-GPU render of the whole range to rounding."""
+    import os
+    import subprocess
+    import sys
+    import textwrap
+    fake = os.path.join(util.ROOT, 'tests', 'libfake_rccl.so')
+    assert os.path.exists(fake), 'tests/libfake_rccl.so is missing: __graft_entry__.build() compiles it'
+    code = textwrap.dedent('''
+        import ctypes, numpy as np, sys
+        import torch      # first: its HIP runtime then serves the library and the stand-in too
+        import ptamd, util
+        from ptamd import scenes, lib
+        b = util.cornell('sky')
+        P = scenes.cornell_params(ptamd.default_params(40, 24))
+        rs = [b.renderer(P) for _ in range(3)]
+        for r in rs: r.set_max_bounces(6)
+        a, c = lib.group_frames(2, 9, 2, 0), lib.group_frames(2, 9, 2, 1)
+        assert a == (2, 5) and c == (5, 9)
+        rs[2].render(P, 2, 9); whole = rs[2].read_accum()
+        rs[2].clear_accum(); rs[2].render(P, *a); part0 = rs[2].read_accum()
+        rs[2].clear_accum(); rs[2].render(P, *c); part1 = rs[2].read_accum()
+        rs[1].render(P, 0, 1)                      # stale contents on rank 1: the group must clear them
+        g = lib.Group(rs[:2])
+        g.render(P, 2, 9)
+        got = rs[0].read_accum()
+        assert np.array_equal(got.view(np.uint32), (part0 + part1).view(np.uint32)), 'reduce is not rank 0 + rank 1'
+        assert np.max(np.abs(got - whole) / np.maximum(np.abs(whole), 1e-6)) <= 1e-4
+        assert np.array_equal(rs[1].read_accum().view(np.uint32), part1.view(np.uint32))      # in place: the other ranks keep their part
+        g.render(P, 9, 11)                          # a second call adds onto context 0 and starts the others from zero again
+        rs[2].clear_accum(); rs[2].render(P, 2, 11); whole2 = rs[2].read_accum()
+        got2 = rs[0].read_accum()
+        assert np.max(np.abs(got2 - whole2) / np.maximum(np.abs(whole2), 1e-6)) <= 1e-4
+        fake = ctypes.CDLL(sys.argv[1])
+        nr, ng = ctypes.c_int(), ctypes.c_int()
+        fake.fake_rccl_calls(ctypes.byref(nr), ctypes.byref(ng))
+        assert (nr.value, ng.value) == (4, 2), (nr.value, ng.value)
+        for r in rs: r.close()                      # contexts first, the group after them
+        g.close()
+        print('group ok')
+    ''')
+    env = dict(os.environ, PTAMD_RCCL_LIBRARY=fake, PTAMD_GROUP_SHARED_GPU='1',
+               PYTHONPATH=os.pathsep.join([os.path.join(util.ROOT, 'cuda-pathtracer_amd', 'python'), os.path.join(util.ROOT, 'tests')]))
+    p = subprocess.run([sys.executable, '-c', code, fake], capture_output=True, text=True, timeout=200, env=env)
+    assert p.returncode == 0 and 'group ok' in p.stdout, p.stdout[-1000:] + p.stderr[-3000:]
+
+
 @pytest.mark.timeout(600)      # three bench processes, each importing torch afresh
 def test_bench_two_ranks_on_one_gpu_match_one_rank():
     """bench.py itself under torch.distributed.run with two ranks sharing the GPU (gloo backend; RCCL needs one GPU per
