@@ -1297,6 +1297,19 @@ void orc_bsdf_sample(const pt_material* M, int inside, const float V[3], const f
     L_out[0] = L.x; L_out[1] = L.y; L_out[2] = L.z; f_out[0] = f.x; f_out[1] = f.y; f_out[2] = f.z; *pdf_out = pdf; *inside_out = in2;
 }
 
+// the same two hooks over arrays (n directions, or the random streams of pixels pixel0 .. pixel0 + n - 1)
+void orc_bsdf_eval_batch(const pt_material* M, int inside, const float V[3], const float N[3], const float* L, int n, float* f_out, float* pdf_out)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) orc_bsdf_eval(M, inside, V, N, L + 3 * (size_t)i, f_out + 3 * (size_t)i, pdf_out + i);
+}
+void orc_bsdf_sample_batch(const pt_material* M, int inside, const float V[3], const float N[3], uint32_t pixel0, int n, int frame,
+                           float* L_out, float* f_out, float* pdf_out, int* inside_out)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) orc_bsdf_sample(M, inside, V, N, pixel0 + (uint32_t)i, frame, L_out + 3 * (size_t)i, f_out + 3 * (size_t)i, pdf_out + i, inside_out + i);
+}
+
 void orc_env_eval(const orc_scene* s, const float d[3], float out[4])
 {
     Scene S = view(s);

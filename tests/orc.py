@@ -239,6 +239,25 @@ def bsdf_sample(mat, inside, V, N, pixel, frame):
     return np.array(list(L), np.float32), np.array(list(f), np.float32), pdf.value, bool(ins.value)
 
 
+def bsdf_eval_batch(mat, inside, V, N, L):
+    """DisneyEval_2 for an array of directions L[n, 3]: returns (f[n, 3], pdf[n])."""
+    m = np.ascontiguousarray(mat, dtype=MAT_DTYPE).reshape(1)
+    L = np.ascontiguousarray(L, np.float32)
+    n = len(L)
+    f, pdf = np.zeros((n, 3), np.float32), np.zeros(n, np.float32)
+    lib().orc_bsdf_eval_batch(_p(m), C.c_int(int(inside)), _f3(V), _f3(N), _p(L), C.c_int(n), _p(f), _p(pdf))
+    return f, pdf
+
+
+def bsdf_sample_batch(mat, inside, V, N, pixel0, n, frame):
+    """DisneySample_2 with the random streams of pixels pixel0 .. pixel0 + n - 1: returns (L[n, 3], f[n, 3], pdf[n], inside'[n])."""
+    m = np.ascontiguousarray(mat, dtype=MAT_DTYPE).reshape(1)
+    L, f = np.zeros((n, 3), np.float32), np.zeros((n, 3), np.float32)
+    pdf, ins = np.zeros(n, np.float32), np.zeros(n, np.int32)
+    lib().orc_bsdf_sample_batch(_p(m), C.c_int(int(inside)), _f3(V), _f3(N), C.c_uint32(pixel0), C.c_int(n), C.c_int(frame), _p(L), _p(f), _p(pdf), _p(ins))
+    return L, f, pdf, ins.astype(bool)
+
+
 def env_eval(scene, d):
     out = (C.c_float * 4)()
     cs = scene.c_scene()

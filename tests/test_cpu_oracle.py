@@ -379,6 +379,119 @@ def test_rough_dielectric_is_nearly_lambertian_and_conserves_energy():
     assert np.all(f == 0)              # no transmission through an opaque surface
 
 
+# Laws the reference's model satisfies by construction, whoever reads it: they pin the restated formulas without
+# sharing the restatement (a misread density, Jacobian or lobe weight breaks them; agreement with the GPU cannot).
+_FAMILIES = {
+    'diffuse_sheen': dict(roughness=0.9, subsurface=0.5, sheen=0.7),
+    'plastic': dict(roughness=0.4),
+    'aniso_metal': dict(roughness=0.4, metallic=1.0, anisotropic=0.8),
+    'clearcoat': dict(roughness=0.6, clearcoat=1.0, clearcoatRoughness=0.3),
+    'all_reflection_lobes': dict(roughness=0.5, metallic=0.3, clearcoat=0.5, clearcoatRoughness=0.4, sheen=0.3, subsurface=0.2),
+    'rough_glass': dict(roughness=0.5, specTrans=1.0, ior=1.5),
+    'glass_in_a_mix': dict(roughness=0.5, metallic=0.3, specTrans=0.4, ior=1.4, clearcoat=0.5, clearcoatRoughness=0.4),
+}
+
+
+def _sphere_grid(nt, nphi):
+    """Midpoints of an equal-area grid over the unit sphere: (directions[nt * nphi, 3], solid angle of a cell)."""
+    ct = (np.arange(nt) + 0.5) / nt * 2 - 1
+    ph = (np.arange(nphi) + 0.5) / nphi * 2 * math.pi
+    CT, PH = np.meshgrid(ct, ph, indexing='ij')
+    st = np.sqrt(1 - CT ** 2)
+    return np.stack([st * np.cos(PH), st * np.sin(PH), CT], -1).reshape(-1, 3).astype(np.float32), 4 * math.pi / (nt * nphi)
+
+
+def _refraction_is_feasible(V, L, eta):
+    """A transmitted direction needs a half vector on which V and L lie on opposite sides (disney.cuh:255-259 builds
+    that vector for any L; EvalMicrofacetRefraction, :198-215, does not check the sides, so it reports a density of a
+    few percent for directions no sample can take)."""
+    H = L.astype(np.float64) + V.astype(np.float64) * eta
+    H /= np.maximum(np.linalg.norm(H, axis=1, keepdims=True), 1e-30)
+    H[H[:, 2] < 0] *= -1
+    return (H @ V.astype(np.float64)) * np.einsum('ij,ij->i', H, L.astype(np.float64)) < 0
+
+
+@pytest.mark.parametrize('family', sorted(_FAMILIES))
+@pytest.mark.parametrize('inside', [0, 1])
+def test_bsdf_density_is_the_density_of_its_sampler(family, inside):
+    """DisneyEval_2's pdf (disney.cuh:234-347) against the directions DisneySample_2 (:348-460) produces: per
+    hemisphere its integral equals the share of samples that land there with a positive density (samples the lobes
+    throw below the horizon are lost, so the integrals fall short of 1 by exactly that share), and a histogram of
+    200 000 sampled directions over 256 equal-area bins follows it (chi-square)."""
+    if inside and _FAMILIES[family].get('specTrans', 0) == 0:
+        pytest.skip('the inside flag only enters through the index ratio of a transmissive material')
+    m = _mat(**_FAMILIES[family])
+    m['baseColor'] = [0.8, 0.6, 0.3]
+    N = np.array([0, 0, 1], np.float32)
+    eta = float(m['ior'][0]) if inside else 1.0 / float(m['ior'][0])
+    for Vn in ([0.3, 0.1, 0.9], [0.8, 0.0, 0.25]):
+        V = np.array(Vn, np.float32); V /= np.linalg.norm(V)
+        nt, nphi = 512, 1024
+        L, dw = _sphere_grid(nt, nphi)
+        _, pdf = orc.bsdf_eval_batch(m, inside, V, N, L)
+        pdf = pdf.astype(np.float64)
+        assert np.all(pdf >= 0) and np.isfinite(pdf).all()
+        feasible = (L[:, 2] > 0) | _refraction_is_feasible(V, L, eta)
+        pdf = np.where(feasible, pdf, 0.0)
+        n = 200000
+        Ls, fs, ps, _ = orc.bsdf_sample_batch(m, inside, V, N, 5000, n, 7)
+        ok = ps > 0
+        assert np.all(np.abs(np.linalg.norm(Ls[ok], axis=1) - 1) < 1e-3)
+        # A direction that a reflection lobe throws below the horizon is evaluated with the refraction density all the same
+        # (DisneyEval_2 looks at the side of L only, :289,324-337), so the lower hemisphere holds samples that density does
+        # not describe. For pure glass they are the few reflections off nearly horizontal facets (0.3 % here; the
+        # tolerance below covers them); in a mix with other lobes they are too many, and the law is held above only.
+        pure_glass = m['specTrans'][0] == 1 and m['metallic'][0] == 0 and m['clearcoat'][0] == 0
+        hemispheres = (1, -1) if (pure_glass or m['specTrans'][0] == 0) else (1,)
+        ok = ok & ((Ls[:, 2] > 0) | _refraction_is_feasible(V, Ls, eta))
+        if len(hemispheres) == 1:
+            pdf = np.where(L[:, 2] > 0, pdf, 0.0)
+            ok = ok & (Ls[:, 2] > 0)
+        for sign in hemispheres:
+            hemi = sign * L[:, 2] > 0
+            integral = pdf[hemi].sum() * dw
+            share = float((ok & (sign * Ls[:, 2] > 0)).mean())
+            sigma = math.sqrt(max(share * (1 - share), 1e-6) / n)
+            # (with glass, directions that end on the other side of the surface than their lobe intends, a refraction off a
+            # steep facet that stays above or a reflection that dips below, are evaluated by the other formula: up to 4 % of
+            # the samples here, for a grazing view from inside the glass)
+            assert abs(integral - share) <= 4 * sigma + (5e-2 if m['specTrans'][0] > 0 else 2e-3), (family, inside, Vn, sign, integral, share)
+        # histogram: 8 bands of cos(theta) x 16 sectors of phi per hemisphere, expected counts by quadrature
+        bands, sectors = 16, 16
+        cell_t = (np.arange(nt) * bands // nt)[:, None] * sectors + (np.arange(nphi) * sectors // nphi)[None, :]
+        expected = np.bincount(cell_t.ravel(), weights=pdf * dw * n, minlength=bands * sectors)
+        st = np.clip((Ls[ok, 2] + 1) / 2 * bands, 0, bands - 1e-9).astype(int)
+        sp = np.clip((np.arctan2(Ls[ok, 1], Ls[ok, 0]) % (2 * math.pi)) / (2 * math.pi) * sectors, 0, sectors - 1e-9).astype(int)
+        observed = np.bincount(st * sectors + sp, minlength=bands * sectors)
+        terms = ((observed - expected) ** 2) / np.maximum(expected, 1e-9)
+        upper = np.arange(bands * sectors) >= bands * sectors // 2
+        big = (expected >= 50) & upper
+        if not (inside and m['specTrans'][0] > 0):      # (from inside glass the stray refractions, up to 4 % of the samples, crowd a few bins)
+            assert big.sum() >= 10 and terms[big].sum() / big.sum() < (4.0 if m['specTrans'][0] > 0 else 1.6), (family, inside, Vn, terms[big].sum(), big.sum())
+        # (below the surface the stray directions described above spoil a bin-by-bin comparison; the hemisphere's share, held
+        # above to 5 %, is what pins the refraction Jacobian and the Fresnel split: a wrong one misses by tens of percent)
+        # nothing is sampled where the density says nothing can be
+        assert observed[expected < 1e-3].sum() <= 2, (family, inside, Vn)
+
+
+@pytest.mark.parametrize('family', ['diffuse_sheen', 'plastic', 'aniso_metal', 'clearcoat', 'all_reflection_lobes'])
+def test_reflection_lobes_are_reciprocal(family):
+    """f(V, L) = f(L, V) for every reflection lobe of the model (Disney diffuse with retro-reflection and the
+    subsurface blend, sheen, GGX with Smith shadowing, the clearcoat): DisneyEval_2 returns f times |L.z|
+    (disney.cuh:346), so f(V, L) / L.z must equal f(L, V) / V.z."""
+    m = _mat(**_FAMILIES[family])
+    m['baseColor'] = [0.8, 0.6, 0.3]
+    N = np.array([0, 0, 1], np.float32)
+    rng = np.random.default_rng(3)
+    for k in range(300):
+        V = rng.normal(0, 1, 3); V[2] = abs(V[2]) + 0.05; V = (V / np.linalg.norm(V)).astype(np.float32)
+        L = rng.normal(0, 1, 3); L[2] = abs(L[2]) + 0.05; L = (L / np.linalg.norm(L)).astype(np.float32)
+        f1, _ = orc.bsdf_eval(m, 0, V, N, L)
+        f2, _ = orc.bsdf_eval(m, 0, L, N, V)
+        a, b = f1 / L[2], f2 / V[2]
+        assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(np.abs(a), 1e-6)), (family, V, L, a, b)
+
+
 def test_sky_gradient_brightest_toward_the_sun():
     sun = np.array([1, 0.7, -1], np.float32); sun /= np.linalg.norm(sun)
     at_sun = orc.sky_gradient(sun, sun)
