@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <atomic>
 #include <vector>
 #include <functional>
 #include <new>
@@ -513,7 +514,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     // union is no larger (in surface area) than the two halves together, as for the two triangles of a quad. Unrelated
     // neighbours (a soup of small triangles) keep a box and a test each.
     std::vector<char> mergeable(dn.size(), 0);
-    bool big_leaf = false;
+    std::atomic<bool> big_leaf{false};       // set from the worker threads of the sweeps below
     auto wide_ref = [&](int ref) -> int {       // binary reference -> wide reference (interior stays >= 0, to be renumbered)
         if (ref < 0) { int n = leaf_count(ref); if (n > 16) big_leaf = true; return wide_leaf(~ref, n > 16 ? 16 : n); }
         if (mergeable[ref] && sub_count[ref] <= leaf_merge && sub_count[ref] <= 16) return wide_leaf(sub_first[ref], sub_count[ref]);
@@ -716,11 +717,12 @@ int pt_build_bvh(pt_ctx* c, int flavour)
         GpuScene g;
         const int stack_capacity = 16 + 48      /* LDS entries + private spill entries of the traversal kernels */;
         int rc = gpu_build_scene(c->d_tri_ref, n, c->leaf_merge, flavour == PT_BVH_GPU_PLOC, flavour == PT_BVH_GPU_PLOC, &g, new_idx.data(), c->stream);
-        if (rc != PT_OK) return rc;
-        if (flavour == PT_BVH_GPU_PLOC && g.stack_need_binary > stack_capacity) {
-            // an agglomerative tree can come out lopsided (clusters swallowing their neighbours one by one); the radix
-            // tree over the same order is bounded by the key length
-            (void)hipFree(g.nodes); (void)hipFree(g.qnodes); (void)hipFree(g.nodes4); (void)hipFree(g.tris);
+        if (rc != PT_OK && flavour != PT_BVH_GPU_PLOC) return rc;
+        if (flavour == PT_BVH_GPU_PLOC && (rc != PT_OK || g.stack_need_binary > stack_capacity)) {
+            // an agglomerative tree can come out lopsided (clusters swallowing their neighbours one by one) or, for
+            // chains of nearest neighbours, not finish within its round limit; the radix tree over the same order is
+            // bounded by the key length and always ends
+            if (rc == PT_OK) { (void)hipFree(g.nodes); (void)hipFree(g.qnodes); (void)hipFree(g.nodes4); (void)hipFree(g.tris); }
             g = GpuScene{};
             rc = gpu_build_scene(c->d_tri_ref, n, c->leaf_merge, false, false, &g, new_idx.data(), c->stream);
             if (rc != PT_OK) return rc;

@@ -493,6 +493,10 @@ static TightBox item_join(const TightBox& a, const TightBox& b)
     return u;
 }
 
+// Twice the centre of a box along an axis, as a sort key. A box with vertices at both infinities has no centre
+// (-inf + inf): it sorts as 0, so that the comparison stays a strict weak order whatever the vertices are.
+static float centre_key(const TightBox& b, int axis) { const float c = b.lo[axis] + b.hi[axis]; return c == c ? c : 0.f; }
+
 struct TopBuilder {
     std::vector<TopItem>& items;
     std::vector<DNode>& nodes; std::vector<TightBox>& tl; std::vector<TightBox>& tr; std::vector<NodeAux>& aux;
@@ -507,7 +511,7 @@ struct TopBuilder {
         // (below 48 levels of lopsided splits the halves are taken by the median: the recursion stays shallow)
         for (int axis = 0; axis < 3 && n > 2; axis++) {
             std::sort(items.begin() + first, items.begin() + last, [axis](const TopItem& a, const TopItem& b) {
-                const float ca = a.box.lo[axis] + a.box.hi[axis], cb = b.box.lo[axis] + b.box.hi[axis];
+                const float ca = centre_key(a.box, axis), cb = centre_key(b.box, axis);
                 return ca < cb || (ca == cb && a.ref < b.ref); });
             suffix.assign((size_t)n + 1, 0.0);
             TightBox acc = items[(size_t)last - 1].box; long long cnt = 0;
@@ -522,7 +526,7 @@ struct TopBuilder {
         if (n > 2) {
             const int axis = best_axis;
             std::sort(items.begin() + first, items.begin() + last, [axis](const TopItem& a, const TopItem& b) {
-                const float ca = a.box.lo[axis] + a.box.hi[axis], cb = b.box.lo[axis] + b.box.hi[axis];
+                const float ca = centre_key(a.box, axis), cb = centre_key(b.box, axis);
                 return ca < cb || (ca == cb && a.ref < b.ref); });
         }
         TightBox cb[2]; int cc[2], ch[2], cref[2];
