@@ -130,8 +130,8 @@ struct pt_ctx {
         hipStream_t stream = nullptr;   // lane 0 runs on the context's stream, the others on their own
         void* block = nullptr;          // one allocation holding every slot array
         size_t block_bytes = 0;
-        float* staging = nullptr;
-        size_t staging_bytes = 0;
+        float* staging[2] = {nullptr, nullptr};     // two sample arrays: frames staged ahead are consumed from one while the next batch fills the other
+        size_t staging_bytes[2] = {0, 0};
         uint32_t* counters = nullptr;
         uint32_t* host_counters = nullptr;   // pinned
         hipEvent_t st_ev[8 * kStageEvents] = {};    // per iteration of a batch: before extend, after each stage kernel
@@ -154,7 +154,7 @@ struct pt_ctx {
     // pt_render_frame renders a few frames ahead into the staging arrays while the caller keeps asking for the next
     // frame of the same view; a staged frame is added to the accumulator when its call comes.
     uint64_t epoch = 0;             // bumped by every call that changes what a sample evaluates to
-    int lookahead_max = 8;          // frames rendered per batch at most (1: no look-ahead)
+    int lookahead_max = 32;         // frames rendered per batch at most (1: no look-ahead)
     struct Ahead {
         bool valid = false;
         uint64_t epoch = 0;
@@ -162,6 +162,18 @@ struct pt_ctx {
         int first = 0, count = 0, next = 0, lanes = 0;
         int streak = 0;             // consecutive calls that continued the previous one
         int last_frame = -2;
+        int buf = 0;                // which staging arrays hold the batch being handed out
+        WfParams w[2];              // that batch's lanes (pixels, staging array)
+        // The batch after it is rendered meanwhile by a worker thread into the other staging arrays, on streams of its
+        // own, so that no call pays for a batch: the caller's stream only ever runs one frame's addition, resolve and copy.
+        std::thread worker;
+        bool pending = false;       // a worker was started for [p_first, p_first + p_count)
+        int p_first = 0, p_count = 0, p_lanes = 0, p_rc = 0;
+        std::string p_error;
+        WfParams p_w[2];
+        hipStream_t stream0 = nullptr;      // stands in for the context's stream in the worker's renders
+        hipEvent_t staged = nullptr;        // recorded by the worker behind its batch
+        hipEvent_t consumed = nullptr;      // recorded on the context's stream behind the last addition from the arrays the worker fills next
     } ahead;
     void* static_scratch = nullptr; // this device's copy of the library's built-in block (pt_trace_closest_noalloc_dev)
     hipError_t static_scratch_error = hipSuccess;
@@ -171,6 +183,24 @@ struct pt_ctx {
     uint64_t extend_launches = 0;
     double stage_ms[PT_STAGE_KERNELS] = {};     // extend, resolve, vertex, miss, shadow, bsdf
 };
+
+// Ends the look-ahead of pt_render_frame: waits for the worker thread that renders the next batch (and for the work it
+// queued), and drops what is staged. Every entry point that changes the scene, the settings or the pool, or renders
+// by itself, starts with it; the frame-loop calls and the read-only image getters do not.
+static void ahead_quiesce(pt_ctx* c)
+{
+    pt_ctx::Ahead& A = c->ahead;
+    if (A.worker.joinable()) {
+        A.worker.join();
+        (void)hipSetDevice(c->device);
+        if (A.stream0) (void)hipStreamSynchronize(A.stream0);
+        for (int i = 1; i < pt_ctx::kMaxLanes; i++) if (c->lanes[i].stream) (void)hipStreamSynchronize(c->lanes[i].stream);
+    }
+    A.pending = false;
+    A.valid = false;
+}
+// the first line of every entry point after which frames staged ahead would be stale
+static void state_change(pt_ctx* c) { ahead_quiesce(c); c->epoch++; }
 
 extern "C" {
 
@@ -234,6 +264,10 @@ void pt_destroy(pt_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    ahead_quiesce(c);
+    if (c->ahead.stream0) (void)hipStreamDestroy(c->ahead.stream0);
+    if (c->ahead.staged) (void)hipEventDestroy(c->ahead.staged);
+    if (c->ahead.consumed) (void)hipEventDestroy(c->ahead.consumed);
     (void)hipStreamSynchronize(c->stream);
     free_scene_geometry(c);
     if (c->d_tri_ref) (void)hipFree(c->d_tri_ref);
@@ -255,7 +289,7 @@ void pt_destroy(pt_ctx* c)
         for (hipEvent_t e : L.st_ev) if (e) (void)hipEventDestroy(e);
         if (L.ready) (void)hipEventDestroy(L.ready);
         if (L.block) (void)hipFree(L.block);
-        if (L.staging) (void)hipFree(L.staging);
+        for (float* p : L.staging) if (p) (void)hipFree(p);
         if (L.counters) (void)hipFree(L.counters);
         if (L.host_counters) (void)hipHostFree(L.host_counters);
         if (i > 0 && L.stream) (void)hipStreamDestroy(L.stream);
@@ -269,7 +303,7 @@ void pt_destroy(pt_ctx* c)
 
 int pt_set_stream(pt_ctx* c, void* s)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c) { set_error("null context"); return PT_ERR_ARG; }
     c->stream = s ? (hipStream_t)s : c->own_stream;
     return PT_OK;
@@ -277,7 +311,7 @@ int pt_set_stream(pt_ctx* c, void* s)
 
 int pt_init(pt_ctx* c, const pt_params* p)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !p) { set_error("pt_init: null argument"); return PT_ERR_ARG; }
     int W = p->windowSize.x, H = p->windowSize.y;
     if (W <= 0 || H <= 0 || (int64_t)W * H > (1 << 28)) { set_error("pt_init: bad window size %dx%d", W, H); return PT_ERR_ARG; }
@@ -305,7 +339,7 @@ int pt_clear_accum(pt_ctx* c)
 
 int pt_upload_triangles(pt_ctx* c, const int* tri_idx, const pt_triangle* tris, int n)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !tris || n <= 0) { set_error("pt_upload_triangles: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     c->tris.assign(tris, tris + n);
@@ -337,7 +371,7 @@ static int tex_slot(const pt_ctx* c, uint64_t handle, uint8_t flag, int comps, c
 
 int pt_upload_materials(pt_ctx* c, const pt_material* mats, int n)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !mats || n <= 0) { set_error("pt_upload_materials: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     std::vector<DMat> dm(n);
@@ -381,7 +415,7 @@ int pt_upload_materials(pt_ctx* c, const pt_material* mats, int n)
 // lays triangles out in leaf order. Interior nodes are numbered in depth-first order.
 int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_used, int n_tri)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !nodes || nodes_used <= 0) { set_error("pt_upload_bvh: bad argument"); return PT_ERR_ARG; }
     if (!c->have_tris || n_tri != (int)c->tris.size()) { set_error("pt_upload_bvh: upload %d triangles first", n_tri); return PT_ERR_STATE; }
     if (root_idx < 0 || root_idx >= nodes_used) { set_error("pt_upload_bvh: bad root"); return PT_ERR_ARG; }
@@ -779,7 +813,7 @@ int pt_build_bvh(pt_ctx* c, int flavour)
 
 int pt_upload_texture(pt_ctx* c, const float* texels, int w, int h, int comps, uint64_t* handle_out)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !texels || !handle_out || w <= 0 || h <= 0 || (comps != 1 && comps != 4)) { set_error("pt_upload_texture: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     // 8-bit image data (every value exactly k/255) is kept as bytes: the sampler rebuilds the same floats
@@ -810,7 +844,7 @@ int pt_upload_texture(pt_ctx* c, const float* texels, int w, int h, int comps, u
 
 int pt_set_texture_packing(pt_ctx* c, int on)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c) { set_error("null context"); return PT_ERR_ARG; }
     c->pack_textures = on != 0;
     return PT_OK;
@@ -834,7 +868,7 @@ int pt_unorm8_probe(pt_ctx* c, float* out256)
 
 int pt_upload_envmap(pt_ctx* c, const float* rgba, const float* cdf, int w, int h, float sum, pt_params* params_io)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || !rgba || !cdf || w <= 0 || h <= 0) { set_error("pt_upload_envmap: bad argument"); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
     c->have_env = false;            // until the whole upload has succeeded; every buffer below belongs to the context
@@ -913,7 +947,7 @@ int pt_upload_envmap(pt_ctx* c, const float* rgba, const float* cdf, int w, int 
 
 int pt_set_env_guides(pt_ctx* c, int on, int* verified_out)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c) { set_error("null context"); return PT_ERR_ARG; }
     c->use_env_guides = on != 0;
     c->use_env_texel_guide = on != 2;        // 2: row and column guides only
@@ -926,7 +960,7 @@ int pt_set_env_guides(pt_ctx* c, int on, int* verified_out)
 
 int pt_set_sky_mode(pt_ctx* c, int mode)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || (mode != PT_SKY_ENVMAP && mode != PT_SKY_SUNSKY)) { set_error("pt_set_sky_mode: bad argument"); return PT_ERR_ARG; }
     c->scene.sky_mode = mode;
     return PT_OK;
@@ -934,7 +968,7 @@ int pt_set_sky_mode(pt_ctx* c, int mode)
 
 int pt_set_max_bounces(pt_ctx* c, int n)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || n < 0) { set_error("pt_set_max_bounces: bad argument"); return PT_ERR_ARG; }
     c->max_bounces = n;
     return PT_OK;
@@ -942,7 +976,7 @@ int pt_set_max_bounces(pt_ctx* c, int n)
 
 int pt_enable_counters(pt_ctx* c, int on)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c) { set_error("null context"); return PT_ERR_ARG; }
     if (on < 0 || on > 2) { set_error("pt_enable_counters: 0, 1 or 2"); return PT_ERR_ARG; }
     c->counting = on;
@@ -1104,7 +1138,7 @@ static WfParams lane_feed_view(const pt_ctx::WfLane& L)
 }
 
 // Sizes a lane's slot pool and staging array for `frames` frames of the pixels dealt to lane `lane` of `n_lanes`.
-static int wf_prepare(pt_ctx* c, pt_ctx::WfLane& L, int frames, int lane, int n_lanes, size_t pool_slots, WfParams* w)
+static int wf_prepare(pt_ctx* c, pt_ctx::WfLane& L, int frames, int lane, int n_lanes, size_t pool_slots, int buf, WfParams* w)
 {
     size_t npix = (size_t)c->W * c->H;
     size_t blocks = (npix + 63) / 64, rem = npix % 64;
@@ -1118,12 +1152,12 @@ static int wf_prepare(pt_ctx* c, pt_ctx::WfLane& L, int frames, int lane, int n_
     if (rc != PT_OK) return rc;
     if (!c->extend_blocks_per_cu) w->extend_blocks = (n_lanes > 1 ? 3 : 5) * c->n_cus;     // room for the other lane's kernels
     size_t sbytes = n_samples * sizeof(float);
-    if (sbytes > L.staging_bytes) {
-        if (L.staging) { (void)hipFree(L.staging); L.staging = nullptr; L.staging_bytes = 0; }
-        HIP_TRY(hipMalloc((void**)&L.staging, sbytes));
-        L.staging_bytes = sbytes;
+    if (sbytes > L.staging_bytes[buf]) {
+        if (L.staging[buf]) { (void)hipFree(L.staging[buf]); L.staging[buf] = nullptr; L.staging_bytes[buf] = 0; }
+        HIP_TRY(hipMalloc((void**)&L.staging[buf], sbytes));
+        L.staging_bytes[buf] = sbytes;
     }
-    w->staging = L.staging;
+    w->staging = L.staging[buf];
     w->n_samples = (uint32_t)n_samples;
     w->n_pixels = (uint32_t)n_pixels;
     w->div_pixels = make_fast_div((uint32_t)n_pixels); w->div_tiles_x = make_fast_div((uint32_t)c->W >> 3); w->div_W = make_fast_div((uint32_t)c->W);
@@ -1172,30 +1206,30 @@ static int effective_chunk_frames(const pt_ctx* c)
     return max_chunk;
 }
 
-static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1, bool hold, int* lanes_used);
+static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1, bool hold, int* lanes_used, int buf, hipStream_t base);
 
 // hold: leave the samples in the staging arrays instead of adding them to the accumulator (the caller adds
 // frames one by one); the range must then fit one staging chunk, because every chunk overwrites the last.
-static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1, bool hold = false, int* lanes_used = nullptr)
+// buf: which of the lanes' two staging arrays receives the samples; base: the stream that plays the context's stream
+// (the first lane runs on it and the render is ordered behind it and ahead of it); null = the context's stream.
+static int render_wavefront(pt_ctx* c, const DCamera& cam, int f0, int f1, bool hold = false, int* lanes_used = nullptr, int buf = 0, hipStream_t base = nullptr)
 {
-    c->ahead.valid = false;         // the staging arrays are about to be overwritten
     if (hold && f1 - f0 > effective_chunk_frames(c)) { set_error("render_wavefront: %d held frames exceed the staging chunk of %d", f1 - f0, effective_chunk_frames(c)); return PT_ERR_ARG; }
-    int rc = render_wavefront_chunks(c, cam, f0, f1, hold, lanes_used);
+    int rc = render_wavefront_chunks(c, cam, f0, f1, hold, lanes_used, buf, base ? base : c->stream);
     if (rc != PT_OK) {
         // kernels of either lane may still be queued on buffers a later call resizes or frees
         for (int i = 0; i < pt_ctx::kMaxLanes; i++) if (c->lanes[i].stream) (void)hipStreamSynchronize(c->lanes[i].stream);
-        c->ahead.valid = false;
     }
     return rc;
 }
 
-static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1, bool hold, int* lanes_used)
+static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1, bool hold, int* lanes_used, int buf, hipStream_t base)
 {
     size_t npix = (size_t)c->W * c->H;
     const int max_chunk = effective_chunk_frames(c);
     DCounters* ctr = c->counting ? c->d_ctr : nullptr;
     if (!c->ev_fork) HIP_TRY(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-    c->lanes[0].stream = c->stream;
+    c->lanes[0].stream = base;
     for (int i = 1; i < pt_ctx::kMaxLanes; i++)
         if (!c->lanes[i].stream) HIP_TRY(hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking));
     size_t pixel_blocks = (npix + 63) / 64;
@@ -1208,11 +1242,11 @@ static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1
         size_t lane_pool_slots = (size_t)c->pool_slots / (size_t)n_lanes;
         if (lane_pool_slots < 256) lane_pool_slots = 256;
         // the other lanes start after everything queued on the context's stream so far (uploads, earlier renders)
-        HIP_TRY(hipEventRecord(c->ev_fork, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_fork, base));
         for (int i = 0; i < n_lanes; i++) {
             pt_ctx::WfLane& L = c->lanes[i];
             if (i > 0) HIP_TRY(hipStreamWaitEvent(L.stream, c->ev_fork, 0));
-            int rc = wf_prepare(c, L, frames, i, n_lanes, lane_pool_slots, &L.w);
+            int rc = wf_prepare(c, L, frames, i, n_lanes, lane_pool_slots, buf, &L.w);
             if (rc != PT_OK) return rc;
             L.w.frame_begin = b;
             HIP_TRY(hipMemsetAsync(L.counters, 0, WF_CTR_WORDS * sizeof(uint32_t), L.stream));
@@ -1283,7 +1317,7 @@ static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1
         // the context's stream continues after the other lanes
         for (int i = 1; i < n_lanes; i++) {
             HIP_TRY(hipEventRecord(c->lanes[i].ready, c->lanes[i].stream));
-            HIP_TRY(hipStreamWaitEvent(c->stream, c->lanes[i].ready, 0));
+            HIP_TRY(hipStreamWaitEvent(base, c->lanes[i].ready, 0));
         }
     }
     return PT_OK;
@@ -1341,7 +1375,7 @@ int pt_set_extend_tuning(pt_ctx* c, int refill_lanes, int leaf_vote, int blocks_
 
 int pt_set_node_width(pt_ctx* c, int width, int leaf_merge)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || (width != 2 && width != 4) || leaf_merge < 1 || leaf_merge > 16) { set_error("pt_set_node_width: width must be 2 or 4, leaf_merge 1..16"); return PT_ERR_ARG; }
     c->node_width = width;
     c->leaf_merge = leaf_merge;         // takes effect at the next pt_upload_bvh / pt_build_bvh
@@ -1351,7 +1385,7 @@ int pt_set_node_width(pt_ctx* c, int width, int leaf_merge)
 
 int pt_set_mode(pt_ctx* c, int mode)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || (mode != PT_MODE_WAVEFRONT && mode != PT_MODE_SINGLE_KERNEL)) { set_error("pt_set_mode: bad argument"); return PT_ERR_ARG; }
     c->mode = mode;
     return PT_OK;
@@ -1359,7 +1393,7 @@ int pt_set_mode(pt_ctx* c, int mode)
 
 int pt_set_lanes(pt_ctx* c, int lanes)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || lanes < 1 || lanes > pt_ctx::kMaxLanes) { set_error("pt_set_lanes: 1 or 2 lanes"); return PT_ERR_ARG; }
     c->n_lanes = lanes;
     c->lanes_forced = true;
@@ -1375,7 +1409,7 @@ int pt_set_drain(pt_ctx* c, int max_rays)
 
 int pt_set_pool(pt_ctx* c, int slots, int chunk_frames)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     if (!c || slots < 64 || chunk_frames < 1) { set_error("pt_set_pool: bad argument"); return PT_ERR_ARG; }
     c->pool_slots = slots;
     c->chunk_frames = chunk_frames;
@@ -1388,6 +1422,7 @@ int pt_render_headless(pt_ctx* c, const pt_params* P, int frame_begin, int frame
     if (rc != PT_OK) return rc;
     if (!P || frame_begin < 0 || frame_end < frame_begin || frame_end > 524288) { set_error("pt_render_headless: bad frame range [%d,%d)", frame_begin, frame_end); return PT_ERR_ARG; }
     HIP_TRY(hipSetDevice(c->device));
+    ahead_quiesce(c);               // the lanes and their staging arrays are about to be used
     DCamera cam;
     if ((rc = make_camera(c, P, &cam)) != PT_OK) return rc;
     HIP_TRY(hipEventRecord(c->ev0, c->stream));
@@ -1426,8 +1461,8 @@ static bool same_view(const pt_params& a, const pt_params& b)
 int pt_set_frame_lookahead(pt_ctx* c, int max_frames)
 {
     if (!c || max_frames < 1 || max_frames > 64) { set_error("pt_set_frame_lookahead: bad argument"); return PT_ERR_ARG; }
+    ahead_quiesce(c);
     c->lookahead_max = max_frames;
-    c->ahead.valid = false;
     return PT_OK;
 }
 
@@ -1442,32 +1477,70 @@ static int render_frame_core(pt_ctx* c, pt_params* P)
     if (P->frameIndex == 0 || !P->isRendering) { if ((rc = pt_clear_accum(c)) != PT_OK) return rc; }
     pt_ctx::Ahead& A = c->ahead;
     const bool can_stage = c->mode == PT_MODE_WAVEFRONT && P->isRendering && !c->counting && !c->stage_timing && c->lookahead_max > 1 &&
-                           P->frameIndex >= 0 && P->frameIndex < 524288 - 64;
+                           P->frameIndex >= 0 && P->frameIndex < 524288 - 128;
     // A caller that keeps asking for the next frame of one view (the reference's main loop while the camera rests,
-    // main.cpp:163-169) gets frames rendered ahead, 2, 4, ... lookahead_max at a time: a batch fills the GPU where a
-    // single 1-spp frame mostly ramps up and down. A staged frame joins the accumulator only when its call comes, in
-    // frame order, so every call returns exactly the image the one-frame-at-a-time loop would.
+    // main.cpp:163-169) gets frames rendered ahead: a batch fills the GPU where a single 1-spp frame mostly ramps up and
+    // down. The first batch (4 frames) is rendered by the call that notices the pattern; from then on a worker thread
+    // renders the next batch (8, 16, ... lookahead_max frames) into the lanes' other staging arrays on streams of its own
+    // while the calls hand out the current one, so no call waits for a batch. A staged frame joins the accumulator only
+    // when its call comes, in frame order, so every call returns exactly the image the one-frame-at-a-time loop would.
     const bool continues = A.last_frame >= 0 && P->frameIndex == A.last_frame + 1 && A.epoch == c->epoch && same_view(*P, A.params);
     A.streak = continues ? A.streak + 1 : 0;
-    bool staged = can_stage && A.valid && continues && P->frameIndex == A.next && A.next < A.first + A.count;
+    if (!continues || !can_stage) { if (A.valid || A.pending) ahead_quiesce(c); }
     DCamera cam;
+    if ((rc = make_camera(c, P, &cam)) != PT_OK) return rc;
+    const int chunk = effective_chunk_frames(c);        // a batch must fit one staging chunk
+    auto batch_size = [&](int after) { int k = after * 2; k = k < 4 ? 4 : k; k = k < c->lookahead_max ? k : c->lookahead_max; return k < chunk ? k : chunk; };
+    // the batch in hand is used up: the one the worker rendered takes its place
+    if (can_stage && continues && A.valid && P->frameIndex == A.first + A.count && A.pending && P->frameIndex == A.p_first) {
+        A.worker.join();
+        A.pending = false;
+        if (A.p_rc != PT_OK) { set_error("%s", A.p_error.c_str()); A.valid = false; return A.p_rc; }
+        HIP_TRY(hipStreamWaitEvent(c->stream, A.staged, 0));
+        A.buf ^= 1;
+        A.first = A.next = A.p_first; A.count = A.p_count; A.lanes = A.p_lanes;
+        for (int i = 0; i < A.lanes; i++) A.w[i] = A.p_w[i];
+    }
+    bool staged = can_stage && continues && A.valid && P->frameIndex == A.next && A.next < A.first + A.count;
     if (can_stage && !staged && A.streak >= 1) {
-        int k = 1 << (A.streak < 6 ? A.streak : 6);
-        k = k < c->lookahead_max ? k : c->lookahead_max;
-        // a batch must stay within one staging chunk: a later chunk would overwrite the frames staged before it
-        const int chunk = effective_chunk_frames(c);
-        k = k < chunk ? k : chunk;
-        if ((rc = make_camera(c, P, &cam)) != PT_OK) return rc;
+        // no batch in hand: render the first one here
+        ahead_quiesce(c);
+        const int k = batch_size(0);
         HIP_TRY(hipEventRecord(c->ev0, c->stream));
         int lanes = 0;
-        if ((rc = render_wavefront(c, cam, P->frameIndex, P->frameIndex + k, true, &lanes)) != PT_OK) return rc;
+        A.buf = 0;
+        if ((rc = render_wavefront(c, cam, P->frameIndex, P->frameIndex + k, true, &lanes, A.buf)) != PT_OK) return rc;
         HIP_TRY(hipEventRecord(c->ev1, c->stream));
         A.valid = true; A.first = A.next = P->frameIndex; A.count = k; A.lanes = lanes;
+        for (int i = 0; i < lanes; i++) A.w[i] = c->lanes[i].w;
         staged = true;
     }
+    if (staged && !A.pending && A.first + A.count < 524288 - 128) {
+        // start the worker on the batch that follows the one in hand
+        if (!A.stream0) HIP_TRY(hipStreamCreateWithFlags(&A.stream0, hipStreamNonBlocking));
+        if (!A.staged) HIP_TRY(hipEventCreateWithFlags(&A.staged, hipEventDisableTiming));
+        if (!A.consumed) HIP_TRY(hipEventCreateWithFlags(&A.consumed, hipEventDisableTiming));
+        // the arrays it fills were handed out before the batch in hand: their last addition is already queued on the
+        // context's stream, and so is everything the scene depends on
+        HIP_TRY(hipEventRecord(A.consumed, c->stream));
+        HIP_TRY(hipStreamWaitEvent(A.stream0, A.consumed, 0));
+        A.p_first = A.first + A.count; A.p_count = batch_size(A.count); A.p_rc = PT_OK; A.p_error.clear();
+        A.pending = true;
+        const int device = c->device, target = A.buf ^ 1;
+        A.worker = std::thread([c, cam, device, target]() {
+            pt_ctx::Ahead& W = c->ahead;
+            int rc = hipSetDevice(device) == hipSuccess ? PT_OK : PT_ERR_HIP;
+            int lanes = 0;
+            if (rc == PT_OK) rc = render_wavefront(c, cam, W.p_first, W.p_first + W.p_count, true, &lanes, target, W.stream0);
+            if (rc == PT_OK && hipEventRecord(W.staged, W.stream0) != hipSuccess) rc = PT_ERR_HIP;
+            W.p_lanes = lanes;
+            for (int i = 0; i < lanes; i++) W.p_w[i] = c->lanes[i].w;
+            W.p_rc = rc;
+            if (rc != PT_OK) W.p_error = pt_last_error();      // messages are per thread
+        });
+    }
     if (staged) {
-        if ((rc = make_camera(c, P, &cam)) != PT_OK) return rc;
-        for (int i = 0; i < A.lanes; i++) launch_wf_accumulate(c->lanes[i].w, cam, c->accum, A.next - A.first, 1, c->stream);
+        for (int i = 0; i < A.lanes; i++) launch_wf_accumulate(A.w[i], cam, c->accum, A.next - A.first, 1, c->stream);
         HIP_TRY(hipGetLastError());
         A.next++;
     } else {
@@ -1635,7 +1708,7 @@ int pt_trace_closest_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* hits_
 // wavefront renderer's extend stage runs. Device pointers.
 int pt_trace_closest_fast_dev(pt_ctx* c, const pt_ray* rays_dev, int n, pt_hit* hits_dev)
 {
-    if (c) c->epoch++;          // frames staged ahead by pt_render_frame are stale after this call
+    if (c) state_change(c);     // frames staged ahead by pt_render_frame are stale after this call
     int rc = check_ready(c, false);
     if (rc != PT_OK) return rc;
     if (n <= 0 || !rays_dev || !hits_dev) { set_error("pt_trace_closest_fast_dev: bad argument"); return PT_ERR_ARG; }

@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(ROOT, 'cuda-pathtracer_amd', 'python')); sys.pat
 import numpy as np, ptamd, util
 from ptamd import scenes
 b = util.atrium()
-W, H, n = 1920, 1080, 64
+W, H, n = 1920, 1080, int(os.environ.get('FRAMES', '512'))      # long enough that the look-ahead's first small batches and the batch left unused at the end do not set the figure
 P = scenes.atrium_params(ptamd.default_params(W, H))
 r = b.renderer(P)
 if os.environ.get('DRAIN'):
