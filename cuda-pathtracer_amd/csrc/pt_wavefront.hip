@@ -677,8 +677,11 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
 // so it runs as a kernel of its own with few registers and many waves per SIMD to hide the chain. Every hit gets
 // its position in the next shadow queue here, and the resolved surface is written straight into that record's
 // vertex arrays; the vertex stage fills in the rest. Rays that left the scene are listed for the miss stage.
+#ifndef PT_RESOLVE_WAVES
+#define PT_RESOLVE_WAVES 5      // (4: -1.7 % on the bench; 6 spills)
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void wf_resolve_kernel(WfParams w, DScene S, DCounters* ctr)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RESOLVE_WAVES))) void wf_resolve_kernel(WfParams w, DScene S, DCounters* ctr)
 {
     const uint32_t n_in = w.counters[WF_CTR_N_P];
     const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(kBlock) void wf_resolve_kernel(WfParams w, DScene S
 // queue: medium event, alpha test, light-sample set-up. A vertex that drew a light sample completes its record
 // where it is; a ray that passed through the surface moves on to the next path queue and leaves a dead record.
 #ifndef PT_VERTEX_WAVES
-#define PT_VERTEX_WAVES 4
+#define PT_VERTEX_WAVES 5       // (4: -1.2 % on the bench; 6 spills: -3.5 %)
 #endif
 // DIRECT: for scenes that draw no light samples (sun/sky mode). The vertex has no visibility walk to wait for, so
 // its bsdf stage (after_light) runs here, on the state in registers, instead of going through a shadow-queue record.
@@ -831,8 +834,11 @@ __global__ __launch_bounds__(kBlock) void wf_miss_kernel(WfParams w, DScene S, D
 // dependent loads (hit -> triangle -> material -> texture -> texels). A finished walk stays where it is and its
 // position goes onto the bsdf list, ordered within the workgroup by the kind of work the bsdf stage will do
 // for it; a walk that goes on (it passed an alpha cut-out or an index-matched surface) moves to the next shadow queue.
+#ifndef PT_SHADOW_WAVES
+#define PT_SHADOW_WAVES 6
+#endif
 template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void wf_shadow_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADOW_WAVES))) void wf_shadow_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
     constexpr int kKinds = 64;
     __shared__ uint32_t s_kind[kKinds];
