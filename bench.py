@@ -67,8 +67,8 @@ def requested_bytes(c, packed_textures):
         'vertex': (144 + 112) * hits + 48 * env,
         # list entry and path record in (52), four environment texels (64), a new camera ray out (48)
         'miss': (52 + 64 + 48) * misses,
-        # walk state in (80), uv words of the shading triangle (32), material (128), alpha/metallic texels; transmittance and state out (32), list entry (4)
-        'shadow': (80 + 32 + 128 + 36) * segments + tap1 * c['tex_taps_r'] * 0.5,
+        # direction, hit and state in (48), uv words of the shading triangle (32), material (128), alpha/metallic texels; state out (16), list entry (4)
+        'shadow': (48 + 32 + 128 + 20) * segments + tap1 * c['tex_taps_r'] * 0.5,
         # list entry and whole record in (196), continuing path out (48)
         'bsdf': (196 + 48) * hits,
     }

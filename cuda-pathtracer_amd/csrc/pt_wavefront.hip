@@ -858,20 +858,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
         const bool have = i < n_in && __float_as_int(sd4.w) != 0;
         Path P;
         P.state = ST_DONE; P.lobes = 0; P.nee_surface = false; P.nee_skip = false;
-        P.light = f3(0.f, 0.f, 0.f);
+        P.light = f3(1.f, 1.f, 1.f); P.env_pdf = 0.f;
         float4 c2 = sd4;
+        // The transmittance (d0) is read only by the few walks that can change it: those inside a medium now, or that
+        // left one earlier (sd.w == 2). For every other walk it is still the (1, 1, 1) its vertex wrote.
+        bool light_loaded = false, light_changed = false;
         if (have) {
-            float4 so4 = w.Sc.so[i], h4 = w.hitS[i], l0 = w.Sc.d0[i];
+            float4 h4 = w.hitS[i];
             c2 = w.Sc.c2[i];
             unpack_flags(P, __float_as_uint(c2.y));
+            if (P.sh_inside || __float_as_int(sd4.w) == 2) {
+                float4 l0 = w.Sc.d0[i];
+                P.light = f3(l0.x, l0.y, l0.z); P.env_pdf = l0.w;
+                light_loaded = true;
+            }
             const SampleId id = decode_sample(w, __float_as_uint(c2.w));
             rng_seed(P.rng, id.pixel, (uint32_t)id.frame, __float_as_uint(c2.z));
-            P.so = f3(so4.x, so4.y, so4.z); P.sd = f3(sd4.x, sd4.y, sd4.z);
-            P.light = f3(l0.x, l0.y, l0.z); P.env_pdf = l0.w;
+            P.so = f3(0.f, 0.f, 0.f); P.sd = f3(sd4.x, sd4.y, sd4.z);
             Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
             Surf info;
             resolve_hit<COUNT>(S, h, P.sd, info, tl.taps, tl.taps_r, true);
+            const bool in_medium = P.sh_inside;
             on_shadow_hit<COUNT>(S, cam, P, info, tl);
+            if (P.state == ST_AFTER && dot(P.light, P.light) <= 0.05f) {
+                // Blocked (or all but): the test of pathtracer.cu:318 is taken here and the record says so through
+                // the flag that skips the light's term, so d0 is not rewritten.
+                P.nee_skip = true;
+            } else light_changed = in_medium && info.hit;
         }
         const bool to_bsdf = have && P.state == ST_AFTER;
         const bool goes_on = have && P.state == ST_SHADOW;
@@ -913,18 +926,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
         a.want[0] = goes_on; a.tail[0] = w.counters + WF_CTR_TAIL_S;
         reserve<1>(a);                              // (its barriers also publish s_list_base and protect s_kind)
         if (to_bsdf) {
-            // the walk's result stays in the record: transmittance, state and the draws it consumed
-            w.Sc.d0[i] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
+            // the walk's result stays in the record: transmittance (where a medium changed it), state and the draws
+            // it consumed
+            if (light_changed) w.Sc.d0[i] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
             w.Sc.c2[i] = make_float4(c2.x, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), c2.w);
             w.bsdf_list[s_list_base + first + rank] = i;
         }
         if (goes_on) {
             const uint32_t j = a.pos[0];
-            w.Sn.so[j] = make_float4(P.so.x, P.so.y, P.so.z, 0.f);
-            w.Sn.sd[j] = sd4;
+            // (P.so holds the step along the ray from the record's origin, see above)
+            const float4 so4 = w.Sc.so[i];
+            const F3 o = f3(so4.x, so4.y, so4.z) + P.so;
+            w.Sn.so[j] = make_float4(o.x, o.y, o.z, 0.f);
+            w.Sn.sd[j] = make_float4(sd4.x, sd4.y, sd4.z, __int_as_float(light_loaded ? 2 : 1));
             w.Sn.c0[j] = w.Sc.c0[i]; w.Sn.c1[j] = w.Sc.c1[i];
             w.Sn.c2[j] = make_float4(c2.x, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), c2.w);
-            w.Sn.d0[j] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
+            w.Sn.d0[j] = light_loaded ? make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf) : w.Sc.d0[i];
             w.Sn.d1[j] = w.Sc.d1[i];
             w.Sn.e0[j] = w.Sc.e0[i]; w.Sn.e1[j] = w.Sc.e1[i]; w.Sn.e2[j] = w.Sc.e2[i]; w.Sn.e3[j] = w.Sc.e3[i]; w.Sn.e4[j] = w.Sc.e4[i];
         }
