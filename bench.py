@@ -192,7 +192,7 @@ def main():
     r.set_max_bounces(args.bounces)
     r.set_mode(0 if args.mode == 'wavefront' else 1)
     if args.pool or args.chunk_frames:
-        r.set_pool(args.pool or (1 << 24), args.chunk_frames or 512)
+        r.set_pool(args.pool or (1 << 25), args.chunk_frames or 512)
     if args.node_width != 4 or args.leaf_merge != 2:
         r.set_node_width(args.node_width, args.leaf_merge)
         if bundle is not None:

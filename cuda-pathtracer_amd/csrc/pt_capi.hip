@@ -99,6 +99,7 @@ struct pt_ctx {
     int drain_rays = 1 << 18;
     int leaf_merge = 2;
     DMat* d_mats = nullptr;
+    std::vector<uint8_t> tex_alpha_one;     // per uploaded texture: four components and alpha exactly 1 in every texel
     DTex* d_tex = nullptr;
     std::vector<DTex> tex_table;
     std::vector<void*> tex_data;
@@ -119,7 +120,7 @@ struct pt_ctx {
     size_t n_nodes = 0, n_nodes4 = 0;
     // wavefront pool
     int mode = PT_MODE_WAVEFRONT;
-    int pool_slots = 1 << 24;
+    int pool_slots = 1 << 25;      // (2^24: +3 % time on the bench, 2^26: -0.5 %; 520 bytes of queue arrays per slot)
     int chunk_frames = 512;         // frames per staging chunk: every chunk pays one ramp-up and one run-down of the pool
     int refill_lanes = 8, leaf_vote = 24, n_cus = 256;
     int extend_blocks_per_cu = 0;   // 0: 5 when one lane runs (all the LDS), 3 when two do
@@ -392,6 +393,11 @@ int pt_upload_materials(pt_ctx* c, const pt_material* mats, int n)
         if ((rc = tex_slot(c, m.metallicTexture, m.use_mapPm, 1, "map_Pm", i, &d.tex_metal)) != PT_OK) return rc;
         if ((rc = tex_slot(c, m.emissiveTexture, m.use_mapKe, 1, "map_Ke", i, &d.tex_emis)) != PT_OK) return rc;
         if ((rc = tex_slot(c, m.normalTexture, m.use_mapNor, 4, "map_Bump", i, &d.tex_normal)) != PT_OK) return rc;
+        // (a filtered lookup in a map whose alpha is 1 everywhere returns exactly 1: the weights of tex_mix are a and
+        // 1 - a, whose rounded sum is 1 for every a in [0, 1])
+        const bool alpha_blocks = d.tex_diffuse ? c->tex_alpha_one[(size_t)d.tex_diffuse - 1] != 0 : !(d.alpha < 1.0f);
+        const bool never_refractive = !(d.strans > 0.f || d.strans < 0.f) || !(fabsf(d.ior - 1.f) <= 0.01f);
+        d.opaque = alpha_blocks && never_refractive ? 1 : 0;
     }
     if (c->have_tris) {
         for (size_t i = 0; i < c->tris.size(); i++)
@@ -836,6 +842,10 @@ int pt_upload_texture(pt_ctx* c, const float* texels, int w, int h, int comps, u
     HIP_TRY(hipMalloc(&d, bytes));
     HIP_TRY(hipMemcpy(d, bytes_ok ? (const void*)packed.data() : (const void*)texels, bytes, hipMemcpyHostToDevice));
     c->tex_data.push_back(d);
+    bool alpha_one = comps == 4;
+    const float one = 1.0f;
+    for (size_t i = 3; alpha_one && i < n; i += 4) alpha_one = memcmp(&texels[i], &one, sizeof(float)) == 0;
+    c->tex_alpha_one.push_back(alpha_one ? 1 : 0);
     DTex t; t.texels = d; t.w = w; t.h = h; t.comps = comps; t.format = bytes_ok ? 1 : 0;
     c->tex_table.push_back(t);
     *handle_out = (uint64_t)c->tex_table.size();
@@ -1064,8 +1074,14 @@ static int stage_blocks_for(const pt_ctx* c, size_t slots)
 }
 
 // Entries every queue array gets for `slots` samples in flight: the pool itself plus the sample ids the stage
-// workgroups can hold in their chunks when the global hand-out runs dry (they are all started at once then).
-static size_t queue_capacity(const pt_ctx* c, size_t slots) { return slots + (size_t)stage_blocks_for(c, slots) * 256; }
+// workgroups can hold in their chunks when the global hand-out runs dry (they are all started at once then). Both
+// are dealt to the kStripes stripes of a queue in blocks of 256, in turn, and a sample stays in its stripe, so every
+// stripe needs room for its share rounded up to whole blocks.
+static size_t queue_capacity(const pt_ctx* c, size_t slots)
+{
+    const size_t per_stripe = ((slots + 255) / 256 + kStripes - 1) / kStripes + ((size_t)stage_blocks_for(c, slots) + kStripes - 1) / kStripes;
+    return per_stripe * kStripes * 256;
+}
 
 // Bytes of a lane's queues: 32 arrays of 16 bytes per entry (two buffers each of the path queue's 3 and the shadow
 // queue's 12, and the two hit arrays), the bsdf list, the miss list, and the workgroups' sample-id chunks.
@@ -1150,7 +1166,7 @@ static int wf_prepare(pt_ctx* c, pt_ctx::WfLane& L, int frames, int lane, int n_
     slots = (slots + 255) / 256 * 256;
     int rc = lane_pool(c, L, slots, w);
     if (rc != PT_OK) return rc;
-    if (!c->extend_blocks_per_cu) w->extend_blocks = (n_lanes > 1 ? 3 : 5) * c->n_cus;     // room for the other lane's kernels
+    if (!c->extend_blocks_per_cu) w->extend_blocks = (n_lanes > 1 ? 4 : 5) * c->n_cus;     // room for the other lane's kernels (3: +0.5 % time, 5: +0.2 %)
     size_t sbytes = n_samples * sizeof(float);
     if (sbytes > L.staging_bytes[buf]) {
         if (L.staging[buf]) { (void)hipFree(L.staging[buf]); L.staging[buf] = nullptr; L.staging_bytes[buf] = 0; }
@@ -1285,7 +1301,9 @@ static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1
                 const uint32_t* hc = L.host_counters;
                 // what the last iteration of the batch left in the queues it appended to
                 // (without light samples the shadow queue holds only records that went through the bsdf stage already)
-                const uint64_t live = (uint64_t)hc[WF_CTR_TAIL_P] + (c->scene.sky_mode == PT_SKY_SUNSKY ? 0u : (uint64_t)hc[WF_CTR_TAIL_S]);
+                uint64_t live = 0;
+                for (int r = 0; r < kStripes; r++)
+                    live += (uint64_t)hc[WF_CTR_TAIL_P + r * kStripeWords] + (c->scene.sky_mode == PT_SKY_SUNSKY ? 0u : (uint64_t)hc[WF_CTR_TAIL_S + r * kStripeWords]);
                 // Nothing more can start once the global hand-out had run dry before the batch was issued and the
                 // batch began by starting the ids the workgroups still held.
                 const bool settled = L.flushed;

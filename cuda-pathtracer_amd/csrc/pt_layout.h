@@ -57,7 +57,11 @@ struct __attribute__((aligned(16))) DMat {
     float rough, aniso, metal, subsurf, sheen, coat, coat_rough, strans, alpha, ior;
     float G; float sigA[3]; float sigS[3];
     int tex_diffuse, tex_rough, tex_metal, tex_emis, tex_normal;
-    int pad[4];
+    // 1 when a visibility walk that hits this material always ends there (pathtracer.cu:279-295): its alpha (the
+    // material's, or that of every texel of its colour map) is 1 or more, so no random number passes the alpha test,
+    // and it cannot count as refractive whatever its metallic map holds (specTrans 0, or an ior away from 1)
+    int opaque;
+    int pad[3];
 };
 static_assert(sizeof(DMat) == 128, "material record must be 128 bytes");
 
@@ -133,26 +137,44 @@ struct WfShadowQueue {
     float4 *e0, *e1, *e2, *e3, *e4; // vertex context: material values and shading normal
 };
 
+// Striped queues. One 32-bit word takes about 90 returning atomic adds per microsecond from the whole chip
+// (tools/micro/atomic_rate.hip: 11.4 ns each, whatever the number of workgroups; words 256 bytes apart are served
+// side by side), and a stage launch over six million records reserves its output positions workgroup by workgroup:
+// 25 000 atomics on one tail word are 0.29 ms, more than the memory traffic of the launch takes. So the position
+// space of every queue and list is dealt in blocks of 256 to kStripes stripes (block B belongs to stripe B mod
+// kStripes), each with a tail word of its own: entry l of stripe r sits at position ((l / 256) * kStripes + r) * 256
+// + l mod 256. A workgroup appends what it makes of an input block to the output stripe with the input block's
+// number, so a sample never leaves its stripe and no stripe ever holds more than it was dealt when the samples
+// were started (the arrays need no slack beyond rounding). Consumers take whole blocks; the blocks at the end of
+// the shorter stripes are partly or wholly empty.
+#ifndef PT_STRIPE_SHIFT
+#define PT_STRIPE_SHIFT 4
+#endif
+constexpr int kStripeShift = PT_STRIPE_SHIFT;
+constexpr int kStripes = 1 << kStripeShift;
+constexpr int kStripeWords = 64;        // words between the counters of neighbouring stripes (256 bytes)
+
 // Device counters of the wavefront loop, one 32-bit word each. The words that take atomics from every workgroup
 // of a launch sit 256 bytes apart: atomics on one cache line are served one after the other.
 enum : int {
     WF_CTR_NEXT_SAMPLE = 0,     // next sample id the global hand-out gives to a workgroup (in chunks)
-    WF_CTR_TAIL_P = 64,         // entries appended to the next path queue so far
-    WF_CTR_TAIL_S = 128,        // entries appended to the next shadow queue so far
-    WF_CTR_TAIL_B = 192,        // entries of the bsdf list
-    WF_CTR_TAIL_M = 576,        // entries of the miss list
-    WF_CTR_SEG_MISS = 640,      // next segment of the miss list
-    WF_CTR_SEG_VERTEX = 704,    // next segment of the records the resolve stage placed in the next shadow queue
-    WF_CTR_RAY_NEXT = 256,      // next block of 256 rays the extend kernel hands to a wave
-    WF_CTR_SEG_PATH = 320,      // next 256-record segment of the current path queue / shadow queue / bsdf list a
-    WF_CTR_SEG_SHADOW = 384,    //   workgroup of the stage kernel takes
-    WF_CTR_SEG_BSDF = 448,
-    WF_CTR_N_P = 512,           // records in the current path queue and shadow queue (set by the planning pass)
-    WF_CTR_N_S = 513,
-    WF_CTR_RAY_CHUNKS = 514,    // blocks of 256 rays in both queues together; the first RAY_P_CHUNKS are path rays
-    WF_CTR_RAY_P_CHUNKS = 515,
-    WF_CTR_LEFTOVER = 516,      // sample ids workgroups still hold in their chunks at the last planning pass
-    WF_CTR_WORDS = 712
+    WF_CTR_RAY_NEXT = 64,       // next block of 256 rays the extend kernel hands to a wave
+    WF_CTR_N_P = 128,           // [kStripes] records per stripe of the current path queue (set by the planning pass)
+    WF_CTR_N_S = 128 + kStripes,        // [kStripes] ... of the current shadow queue
+    WF_CTR_RAY_CHUNKS = 128 + 2 * kStripes,     // blocks of 256 positions in both queues together; the first RAY_P_CHUNKS belong to the path queue
+    WF_CTR_RAY_P_CHUNKS = WF_CTR_RAY_CHUNKS + 1,
+    WF_CTR_LEFTOVER = WF_CTR_RAY_CHUNKS + 2,    // sample ids workgroups still hold in their chunks at the last planning pass
+    // families of kStripes words, kStripeWords apart: word of stripe r = family + r * kStripeWords
+    WF_CTR_TAIL_P = 192,                                        // entries appended to the next path queue so far
+    WF_CTR_TAIL_S = WF_CTR_TAIL_P + kStripes * kStripeWords,    // ... to the next shadow queue
+    WF_CTR_TAIL_B = WF_CTR_TAIL_S + kStripes * kStripeWords,    // entries of the bsdf list
+    WF_CTR_TAIL_M = WF_CTR_TAIL_B + kStripes * kStripeWords,    // entries of the miss list
+    WF_CTR_SEG_PATH = WF_CTR_TAIL_M + kStripes * kStripeWords,  // next block of the stripe a workgroup of the resolve stage takes
+    WF_CTR_SEG_VERTEX = WF_CTR_SEG_PATH + kStripes * kStripeWords,
+    WF_CTR_SEG_MISS = WF_CTR_SEG_VERTEX + kStripes * kStripeWords,
+    WF_CTR_SEG_SHADOW = WF_CTR_SEG_MISS + kStripes * kStripeWords,
+    WF_CTR_SEG_BSDF = WF_CTR_SEG_SHADOW + kStripes * kStripeWords,
+    WF_CTR_WORDS = WF_CTR_SEG_BSDF + kStripes * kStripeWords
 };
 // Division of a 32-bit unsigned number by a divisor fixed at launch (Granlund and Montgomery, "Division by invariant
 // integers using multiplication", figure 4.1): exact for every numerator, five integer instructions instead of the
@@ -176,7 +198,7 @@ struct WfParams {
     uint32_t* wg_chunk;             // [stage_blocks][2] cursor/end of the sample-id chunk each persistent workgroup owns
     uint32_t* counters;
     float* staging;                 // n_frames * W * H sample values of the current chunk
-    int capacity;                   // entries every queue array has room for (a multiple of 256)
+    int capacity;                   // entries every queue array has room for (a multiple of 256 * kStripes)
     int n_slots;                    // samples in flight at most (before the workgroups' leftover ids are started)
     int stage_blocks;               // workgroups of a stage launch
     uint32_t n_samples;

@@ -228,12 +228,22 @@ PT_DEV void finish_and_regenerate(const WfParams& w, const DCamera& cam, Path& P
     if (threadIdx.x == 0) { cw[0] = s_chunk[0]; cw[1] = s_chunk[1]; }
 }
 
+// Entry l of stripe r of a striped queue or list (see kStripes).
+PT_DEV uint32_t stripe_pos(uint32_t r, uint32_t l) { return ((((l >> 8) << kStripeShift) | r) << 8) | (l & 255u); }
+// Entries in use of block B of a striped array whose stripes hold counts[0..kStripes) entries.
+PT_DEV uint32_t block_fill(uint32_t B, const uint32_t* counts)
+{
+    const uint32_t n = counts[B & (uint32_t)(kStripes - 1)], base = (B >> kStripeShift) << 8;
+    return n > base ? (n - base < 256u ? n - base : 256u) : 0u;
+}
+
 // Queue positions for the lanes of a workgroup that append to a queue: the lanes for which `want` holds get
-// consecutive positions, in thread order, from one atomic on the queue's tail word. Every thread of the workgroup
-// must call it (it synchronises); the others get kNone. Up to four queues at once share the barriers.
+// consecutive entries of stripe r, in thread order, from one atomic on the stripe's tail word (tail[k] names the
+// family). Every thread of the workgroup must call it (it synchronises); the others get kNone. Up to four queues
+// at once share the barriers.
 struct Appends { bool want[4]; uint32_t* tail[4]; uint32_t pos[4]; };
 template <int N>
-PT_DEV void reserve(Appends& a)
+PT_DEV void reserve(Appends& a, uint32_t r)
 {
     __shared__ uint32_t s_cnt[4][kBlock / 64];
     __shared__ uint32_t s_base[4];
@@ -251,7 +261,7 @@ PT_DEV void reserve(Appends& a)
             uint32_t total = 0;
 #pragma unroll
             for (int j = 0; j < kBlock / 64; j++) total += s_cnt[k][j];
-            s_base[k] = total ? atomicAdd(a.tail[k], total) : 0u;
+            s_base[k] = total ? atomicAdd(a.tail[k] + r * (uint32_t)kStripeWords, total) : 0u;
         }
     }
     __syncthreads();
@@ -260,20 +270,71 @@ PT_DEV void reserve(Appends& a)
         uint32_t woff = 0;
 #pragma unroll
         for (int j = 0; j < kBlock / 64; j++) if (j < wid) woff += s_cnt[k][j];
-        a.pos[k] = a.want[k] ? s_base[k] + woff + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull)) : kNone;
+        a.pos[k] = a.want[k] ? stripe_pos(r, s_base[k] + woff + (uint32_t)__popcll(m[k] & ((1ull << lane) - 1ull))) : kNone;
     }
-    __syncthreads();                    // the counts are reused by the caller's next segment
+    __syncthreads();                    // the counts are reused by the caller's next block
 }
 
-// The next 256-record segment of a stage's input for this workgroup (every thread must call it).
-PT_DEV uint32_t next_segment(uint32_t* cursor)
+// How a workgroup of a stage launch takes its input. The stripes' block cursors (the family `cursors`) are handed
+// out by atomics; a workgroup takes the blocks of one stripe, starting with the stripe of its own number, so the
+// workgroups of a launch spread their atomics evenly over the stripes' words, and moves to the next stripe that has
+// blocks left when its own runs out (it then looks at all the cursors at once: plain loads, one latency).
+//   first_block: every thread calls it once. Copies the stripes' record counts (count_words[r * count_stride]) to
+//     counts[] in LDS and picks the first stripe. A workgroup that starts when everything is taken (the later
+//     workgroups of a launch, which wait for a place on the chip until the earlier ones leave) finds that out here
+//     with one round of loads and no atomic.
+//   next_block: every thread calls it per block; returns the block or kNone. The atomic for the block after this one
+//     goes out at once and is waited for only at the next call, behind the work on this block.
+struct BlockCursor { uint32_t r, k; };      // (thread 0's) stripe in hand, and what its cursor returned for the next block
+PT_DEV uint32_t blocks_of(uint32_t records) { return (records + 255u) >> 8; }
+PT_DEV uint32_t stripe_with_blocks_after(uint32_t r, const uint32_t* cursors, const uint32_t* counts, bool including_r)
 {
-    __shared__ uint32_t s_seg;
-    if (threadIdx.x == 0) s_seg = atomicAdd(cursor, 1u);
+    uint32_t cur[kStripes];
+#pragma unroll
+    for (int j = 0; j < kStripes; j++) cur[j] = __hip_atomic_load(cursors + j * kStripeWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t next = kNone;
+#pragma unroll
+    for (int j = kStripes - 1; j >= 0; j--) {           // the nearest one wins
+        if (j == 0 && !including_r) break;
+        const uint32_t q = (r + (uint32_t)j) & (uint32_t)(kStripes - 1);
+        uint32_t cq = 0;
+#pragma unroll
+        for (int t = 0; t < kStripes; t++) if ((uint32_t)t == q) cq = cur[t];
+        if (cq < blocks_of(counts[q])) next = q;
+    }
+    return next;
+}
+PT_DEV BlockCursor first_block(uint32_t* cursors, const uint32_t* count_words, uint32_t count_stride, uint32_t* counts)
+{
+    if (threadIdx.x < kStripes) counts[threadIdx.x] = count_words[threadIdx.x * count_stride];
     __syncthreads();
-    const uint32_t seg = s_seg;
+    BlockCursor c; c.r = kNone; c.k = 0;
+    if (threadIdx.x == 0) {
+        c.r = stripe_with_blocks_after(blockIdx.x & (uint32_t)(kStripes - 1), cursors, counts, true);
+        if (c.r != kNone) c.k = atomicAdd(cursors + c.r * (uint32_t)kStripeWords, 1u);
+    }
+    return c;
+}
+PT_DEV uint32_t next_block(uint32_t* cursors, const uint32_t* counts, BlockCursor& c)
+{
+    __shared__ uint32_t s_blk;
+    if (threadIdx.x == 0) {
+        uint32_t blk = kNone;
+        while (c.r != kNone) {
+            if (c.k < blocks_of(counts[c.r])) {
+                blk = (c.k << kStripeShift) | c.r;
+                c.k = atomicAdd(cursors + c.r * (uint32_t)kStripeWords, 1u);
+                break;
+            }
+            c.r = stripe_with_blocks_after(c.r, cursors, counts, false);
+            if (c.r != kNone) c.k = atomicAdd(cursors + c.r * (uint32_t)kStripeWords, 1u);
+        }
+        s_blk = blk;
+    }
     __syncthreads();
-    return seg;
+    const uint32_t blk = s_blk;
+    __syncthreads();
+    return blk;
 }
 
 template <bool COUNT>
@@ -321,7 +382,7 @@ __global__ __launch_bounds__(kBlock) void wf_generate_kernel(WfParams w, DCamera
     }
     Appends a;
     a.want[0] = have; a.tail[0] = w.counters + WF_CTR_TAIL_P;
-    reserve<1>(a);
+    reserve<1>(a, blockIdx.x & (uint32_t)(kStripes - 1));     // 256 ids to a stripe, in turn
     if (have) store_path(w.Pn, a.pos[0], P, s);
     if (blockIdx.x == 0 && threadIdx.x == 0) w.counters[WF_CTR_NEXT_SAMPLE] = n_start;
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -346,16 +407,27 @@ __global__ __launch_bounds__(kBlock) void wf_plan_kernel(uint32_t* __restrict__ 
     for (int o = 32; o > 0; o >>= 1) lsum += (uint32_t)__shfl_down((int)lsum, o, 64);
     if (lane == 0) s_left[wid] = lsum;
     __syncthreads();
+    // per stripe: what was appended becomes the current count, the tails and block cursors start over
+    uint32_t bP = 0, bS = 0;
+    if (tid < kStripes) {
+        uint32_t* f = counters + tid * kStripeWords;
+        const uint32_t nP = f[WF_CTR_TAIL_P], nS = no_walks ? 0u : f[WF_CTR_TAIL_S];
+        counters[WF_CTR_N_P + tid] = nP; counters[WF_CTR_N_S + tid] = nS;
+        f[WF_CTR_TAIL_P] = 0; f[WF_CTR_TAIL_S] = 0; f[WF_CTR_TAIL_B] = 0; f[WF_CTR_TAIL_M] = 0;
+        f[WF_CTR_SEG_PATH] = 0; f[WF_CTR_SEG_SHADOW] = 0; f[WF_CTR_SEG_BSDF] = 0; f[WF_CTR_SEG_MISS] = 0; f[WF_CTR_SEG_VERTEX] = 0;
+        bP = (nP + 255u) >> 8; bS = (nS + 255u) >> 8;
+    }
+    // the queues extend as far as their longest stripe (the first wave holds every stripe)
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t oP = (uint32_t)__shfl_down((int)bP, o, 64), oS = (uint32_t)__shfl_down((int)bS, o, 64);
+        bP = oP > bP ? oP : bP; bS = oS > bS ? oS : bS;
+    }
     if (tid == 0) {
         uint32_t leftover = 0;
         for (int j = 0; j < kBlock / 64; j++) leftover += s_left[j];
-        const uint32_t nP = counters[WF_CTR_TAIL_P], nS = no_walks ? 0u : counters[WF_CTR_TAIL_S];
-        counters[WF_CTR_N_P] = nP; counters[WF_CTR_N_S] = nS;
-        counters[WF_CTR_TAIL_P] = 0; counters[WF_CTR_TAIL_S] = 0; counters[WF_CTR_TAIL_B] = 0; counters[WF_CTR_TAIL_M] = 0;
         counters[WF_CTR_RAY_NEXT] = 0;
-        counters[WF_CTR_SEG_PATH] = 0; counters[WF_CTR_SEG_SHADOW] = 0; counters[WF_CTR_SEG_BSDF] = 0; counters[WF_CTR_SEG_MISS] = 0; counters[WF_CTR_SEG_VERTEX] = 0;
-        counters[WF_CTR_RAY_P_CHUNKS] = (nP + kBlock - 1) / kBlock;
-        counters[WF_CTR_RAY_CHUNKS] = (nP + kBlock - 1) / kBlock + (nS + kBlock - 1) / kBlock;
+        counters[WF_CTR_RAY_P_CHUNKS] = bP << kStripeShift;
+        counters[WF_CTR_RAY_CHUNKS] = (bP + bS) << kStripeShift;
         counters[WF_CTR_LEFTOVER] = leftover;
     }
 }
@@ -404,7 +476,9 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     uint32_t chunk_next = 0, chunk_end = 0;      // wave-uniform
     bool chunk_shadow = false;                   // wave-uniform: the block in hand belongs to the shadow queue
     const uint32_t n_chunks = w.counters[WF_CTR_RAY_CHUNKS], n_pchunks = w.counters[WF_CTR_RAY_P_CHUNKS];
-    const uint32_t n_path = w.counters[WF_CTR_N_P], n_shadow = w.counters[WF_CTR_N_S];
+    __shared__ uint32_t s_count[2 * kStripes];      // records per stripe of the path queue, then of the shadow queue
+    if (tid < 2 * kStripes) s_count[tid] = w.counters[WF_CTR_N_P + tid];
+    __syncthreads();
     const uint32_t n_small = n_chunks < PT_TAIL_FACTOR * gridDim.x ? n_chunks : PT_TAIL_FACTOR * gridDim.x, n_big = n_chunks - n_small;
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
 #if PT_STAMPS
@@ -482,8 +556,11 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                     uint32_t blk = li, off = 0, len = kRayChunk;
                     if (li >= n_big) { const uint32_t j = li - n_big; blk = n_big + (j >> 2); off = (j & 3u) * (uint32_t)(kRayChunk / 4); len = kRayChunk / 4; }
                     chunk_shadow = blk >= n_pchunks;
-                    chunk_next = (chunk_shadow ? blk - n_pchunks : blk) * (uint32_t)kRayChunk + off;
-                    chunk_end = chunk_next + len;
+                    const uint32_t B = chunk_shadow ? blk - n_pchunks : blk;
+                    // (the block may be partly or wholly empty: its stripe is shorter than the longest one)
+                    const uint32_t fill = block_fill(B, s_count + (chunk_shadow ? kStripes : 0));
+                    chunk_next = B * (uint32_t)kRayChunk + off;
+                    chunk_end = chunk_next + (fill > off ? (fill - off < len ? fill - off : len) : 0u);
                 }
             }
             const uint32_t avail = chunk_end - chunk_next;
@@ -617,7 +694,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
             if (cur == PT_TRAV_EMPTY) retire();
         }
         // ---- new rays for the lanes that were idle
-        if (got && (chunk_shadow ? (idx < n_shadow && __float_as_int(rd4.w) != 0) : idx < n_path)) {
+        if (got && (!chunk_shadow || __float_as_int(rd4.w) != 0)) {
             slot = idx | (chunk_shadow ? 0x80000000u : 0u);
             o = f3(ro4.x, ro4.y, ro4.z); d = f3(rd4.x, rd4.y, rd4.z);
             best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
@@ -683,14 +760,15 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RESOLVE_WAVES))) void wf_resolve_kernel(WfParams w, DScene S, DCounters* ctr)
 {
-    const uint32_t n_in = w.counters[WF_CTR_N_P];
-    const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
+    __shared__ uint32_t counts[kStripes];
+    BlockCursor bc = first_block(w.counters + WF_CTR_SEG_PATH, w.counters + WF_CTR_N_P, 1, counts);
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
-        const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_PATH);
-        if (seg >= n_seg) break;                    // uniform over the workgroup
-        const uint32_t i = seg * kBlock + threadIdx.x;
-        const bool have = i < n_in;
+        const uint32_t blk = next_block(w.counters + WF_CTR_SEG_PATH, counts, bc);
+        if (blk == kNone) break;                    // uniform over the workgroup
+        const uint32_t stripe = blk & (uint32_t)(kStripes - 1);
+        const uint32_t i = blk * kBlock + threadIdx.x;
+        const bool have = threadIdx.x < block_fill(blk, counts);
         Hit h; h.t = 0.f; h.tri = PT_NO_TRI; h.u = 0.f; h.v = 0.f;
         if (have) { float4 h4 = w.hitP[i]; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w; }
         const bool hit = have && h.tri != PT_NO_TRI;
@@ -705,7 +783,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RESOL
         Appends a;
         a.want[0] = hit; a.tail[0] = w.counters + WF_CTR_TAIL_S;
         a.want[1] = have && !hit; a.tail[1] = w.counters + WF_CTR_TAIL_M;
-        reserve<2>(a);
+        reserve<2>(a, stripe);
         if (hit) {
             const uint32_t j = a.pos[0];
             const Mat& m = info.m;
@@ -734,15 +812,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RESOL
 template <bool COUNT, bool DIRECT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTEX_WAVES))) void wf_vertex_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
-    const uint32_t n_in = w.counters[WF_CTR_TAIL_S];      // the records the resolve stage allocated; nothing else has appended yet
-    const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
+    // the records the resolve stage allocated; nothing else has appended yet
+    __shared__ uint32_t s_counts[kStripes];
+    BlockCursor bc = first_block(w.counters + WF_CTR_SEG_VERTEX, w.counters + WF_CTR_TAIL_S, kStripeWords, s_counts);
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
     for (;;) {
-        const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_VERTEX);
-        if (seg >= n_seg) break;
-        const uint32_t j = seg * kBlock + threadIdx.x;
-        const bool have = j < n_in;
+        const uint32_t blk = next_block(w.counters + WF_CTR_SEG_VERTEX, s_counts, bc);
+        if (blk == kNone) break;
+        const uint32_t stripe = blk & (uint32_t)(kStripes - 1);
+        const uint32_t j = blk * kBlock + threadIdx.x;
+        const bool have = threadIdx.x < block_fill(blk, s_counts);
         Path P;
         SampleId id = {0, 0, 0, 0u, 0u};
         uint32_t sample = kNone;
@@ -778,7 +858,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTE
         Appends ap;
         ap.want[0] = alive && P.state == ST_PATH; ap.tail[0] = w.counters + WF_CTR_TAIL_P;
         ap.want[1] = alive && P.state == ST_AFTER; ap.tail[1] = w.counters + WF_CTR_TAIL_B;
-        reserve<2>(ap);
+        reserve<2>(ap, stripe);
         if (ap.want[0]) store_path(w.Pn, ap.pos[0], P, sample);
         if (stays) {
             w.Sn.so[j] = make_float4(P.so.x, P.so.y, P.so.z, 0.f);
@@ -801,15 +881,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTE
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) void wf_miss_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
-    const uint32_t n_in = w.counters[WF_CTR_TAIL_M];
-    const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
+    __shared__ uint32_t s_counts[kStripes];
+    BlockCursor bc = first_block(w.counters + WF_CTR_SEG_MISS, w.counters + WF_CTR_TAIL_M, kStripeWords, s_counts);
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
     for (;;) {
-        const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_MISS);
-        if (seg >= n_seg) break;
-        const uint32_t k = seg * kBlock + threadIdx.x;
-        const bool have = k < n_in;
+        const uint32_t blk = next_block(w.counters + WF_CTR_SEG_MISS, s_counts, bc);
+        if (blk == kNone) break;
+        const uint32_t stripe = blk & (uint32_t)(kStripes - 1);
+        const uint32_t k = blk * kBlock + threadIdx.x;
+        const bool have = threadIdx.x < block_fill(blk, s_counts);
         Path P;
         SampleId id = {0, 0, 0, 0u, 0u};
         uint32_t sample = kNone;
@@ -821,7 +902,7 @@ __global__ __launch_bounds__(kBlock) void wf_miss_kernel(WfParams w, DScene S, D
         finish_and_regenerate<COUNT>(w, cam, P, sample, id, have, nsamples);
         Appends a;
         a.want[0] = have && P.state == ST_PATH; a.tail[0] = w.counters + WF_CTR_TAIL_P;
-        reserve<1>(a);
+        reserve<1>(a, stripe);
         if (a.want[0]) store_path(w.Pn, a.pos[0], P, sample);
     }
     flush_tally<COUNT>(ctr, tl, nsamples);
@@ -843,19 +924,21 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
     constexpr int kKinds = 64;
     __shared__ uint32_t s_kind[kKinds];
     __shared__ uint32_t s_list_base;
-    const uint32_t n_in = w.counters[WF_CTR_N_S];
-    const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
+    __shared__ uint32_t counts[kStripes];
+    BlockCursor bc = first_block(w.counters + WF_CTR_SEG_SHADOW, w.counters + WF_CTR_N_S, 1, counts);
     const int lane = (int)(threadIdx.x & 63u);
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
         if (threadIdx.x < kKinds) s_kind[threadIdx.x] = 0u;
-        const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_SHADOW);      // (its barriers also publish the cleared counts)
-        if (seg >= n_seg) break;
-        const uint32_t i = seg * kBlock + threadIdx.x;
+        const uint32_t blk = next_block(w.counters + WF_CTR_SEG_SHADOW, counts, bc);      // (its barriers also publish the cleared counts)
+        if (blk == kNone) break;
+        const uint32_t stripe = blk & (uint32_t)(kStripes - 1);
+        const uint32_t i = blk * kBlock + threadIdx.x;
+        const bool in_block = threadIdx.x < block_fill(blk, counts);
         float4 sd4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < n_in) sd4 = w.Sc.sd[i];
-        // a record without a pending ray was handed to the bsdf stage when it was written (see wf_path_kernel)
-        const bool have = i < n_in && __float_as_int(sd4.w) != 0;
+        if (in_block) sd4 = w.Sc.sd[i];
+        // a record without a pending ray was handed to the bsdf stage when it was written (see wf_vertex_kernel)
+        const bool have = in_block && __float_as_int(sd4.w) != 0;
         Path P;
         P.state = ST_DONE; P.lobes = 0; P.nee_surface = false; P.nee_skip = false;
         P.light = f3(1.f, 1.f, 1.f); P.env_pdf = 0.f;
@@ -872,19 +955,32 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
                 P.light = f3(l0.x, l0.y, l0.z); P.env_pdf = l0.w;
                 light_loaded = true;
             }
-            const SampleId id = decode_sample(w, __float_as_uint(c2.w));
-            rng_seed(P.rng, id.pixel, (uint32_t)id.frame, __float_as_uint(c2.z));
             P.so = f3(0.f, 0.f, 0.f); P.sd = f3(sd4.x, sd4.y, sd4.z);
             Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
-            Surf info;
-            resolve_hit<COUNT>(S, h, P.sd, info, tl.taps, tl.taps_r, true);
             const bool in_medium = P.sh_inside;
-            on_shadow_hit<COUNT>(S, cam, P, info, tl);
+            // A material marked opaque at upload ends the walk whatever the hit point: the alpha test draws its
+            // number and fails, the transmittance is zero (pathtracer.cu:279-295). Most hits are of this kind and
+            // skip the texture coordinates, the material record, the texels and the random-number block.
+            bool opaque = false;
+            if (!COUNT && h.tri != PT_NO_TRI) opaque = S.mats[S.tri_ref[h.tri].matIndex].opaque != 0;
+            if (opaque) {
+                P.rng.draws = __float_as_uint(c2.z) + 1u;
+                P.light = f3(0.f, 0.f, 0.f);
+                P.state = ST_AFTER;
+            } else {
+                const SampleId id = decode_sample(w, __float_as_uint(c2.w));
+                rng_seed(P.rng, id.pixel, (uint32_t)id.frame, __float_as_uint(c2.z));
+                Surf info;
+                resolve_hit<COUNT>(S, h, P.sd, info, tl.taps, tl.taps_r, true);
+                on_shadow_hit<COUNT>(S, cam, P, info, tl);
+                light_changed = in_medium && info.hit;
+            }
             if (P.state == ST_AFTER && dot(P.light, P.light) <= 0.05f) {
                 // Blocked (or all but): the test of pathtracer.cu:318 is taken here and the record says so through
                 // the flag that skips the light's term, so d0 is not rewritten.
                 P.nee_skip = true;
-            } else light_changed = in_medium && info.hit;
+                light_changed = false;
+            }
         }
         const bool to_bsdf = have && P.state == ST_AFTER;
         const bool goes_on = have && P.state == ST_SHADOW;
@@ -921,16 +1017,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
         }
         const uint32_t first = (uint32_t)__shfl((int)(incl - held), (int)kind, 64);
         const uint32_t listed = (uint32_t)__shfl((int)incl, 63, 64);
-        if (threadIdx.x == 0) s_list_base = listed ? atomicAdd(w.counters + WF_CTR_TAIL_B, listed) : 0u;
+        if (threadIdx.x == 0) s_list_base = listed ? atomicAdd(w.counters + WF_CTR_TAIL_B + stripe * (uint32_t)kStripeWords, listed) : 0u;
         Appends a;
         a.want[0] = goes_on; a.tail[0] = w.counters + WF_CTR_TAIL_S;
-        reserve<1>(a);                              // (its barriers also publish s_list_base and protect s_kind)
+        reserve<1>(a, stripe);                      // (its barriers also publish s_list_base and protect s_kind)
         if (to_bsdf) {
             // the walk's result stays in the record: transmittance (where a medium changed it), state and the draws
             // it consumed
             if (light_changed) w.Sc.d0[i] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
             w.Sc.c2[i] = make_float4(c2.x, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), c2.w);
-            w.bsdf_list[s_list_base + first + rank] = i;
+            w.bsdf_list[stripe_pos(stripe, s_list_base + first + rank)] = i;
         }
         if (goes_on) {
             const uint32_t j = a.pos[0];
@@ -958,15 +1054,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_BSDF_WAVES))) void wf_bsdf_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
-    const uint32_t n_in = w.counters[WF_CTR_TAIL_B];
-    const uint32_t n_seg = (n_in + kBlock - 1) / kBlock;
+    __shared__ uint32_t s_counts[kStripes];
+    BlockCursor bc = first_block(w.counters + WF_CTR_SEG_BSDF, w.counters + WF_CTR_TAIL_B, kStripeWords, s_counts);
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
     for (;;) {
-        const uint32_t seg = next_segment(w.counters + WF_CTR_SEG_BSDF);
-        if (seg >= n_seg) break;
-        const uint32_t k = seg * kBlock + threadIdx.x;
-        const bool have = k < n_in;
+        const uint32_t blk = next_block(w.counters + WF_CTR_SEG_BSDF, s_counts, bc);
+        if (blk == kNone) break;
+        const uint32_t stripe = blk & (uint32_t)(kStripes - 1);
+        const uint32_t k = blk * kBlock + threadIdx.x;
+        const bool have = threadIdx.x < block_fill(blk, s_counts);
         Path P;
         SampleId id = {0, 0, 0, 0u, 0u};
         uint32_t sample = kNone;
@@ -982,7 +1079,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_BSDF_
         finish_and_regenerate<COUNT>(w, cam, P, sample, id, finished, nsamples);
         Appends a;
         a.want[0] = have && P.state == ST_PATH; a.tail[0] = w.counters + WF_CTR_TAIL_P;
-        reserve<1>(a);
+        reserve<1>(a, stripe);
         if (a.want[0]) store_path(w.Pn, a.pos[0], P, sample);
     }
     flush_tally<COUNT>(ctr, tl, nsamples);
@@ -1016,7 +1113,7 @@ __global__ __launch_bounds__(kBlock) void wf_flush_leftover_kernel(WfParams w, D
     }
     Appends a;
     a.want[0] = have; a.tail[0] = w.counters + WF_CTR_TAIL_P;
-    reserve<1>(a);
+    reserve<1>(a, blockIdx.x & (uint32_t)(kStripes - 1));     // (the queue arrays have room for one chunk per workgroup dealt this way)
     if (have) store_path(w.Pn, a.pos[0], P, s);
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     flush_tally<COUNT>(ctr, tl, nsamples);
@@ -1026,24 +1123,26 @@ __global__ __launch_bounds__(kBlock) void wf_flush_leftover_kernel(WfParams w, D
 // End of a render: every sample id has been started and few records are left. Another hundred stage launches
 // for the longest paths would cost their launch latencies in sequence; instead each remaining record runs its
 // sample to the end in one kernel (the same state machine, one path per lane, traversal with the LDS stack).
-// Lane q takes record q of the path queue, or record q - n_path of the shadow queue.
+// Workgroup b takes block b of the path queue, or block b - (blocks of the path queue) of the shadow queue.
 template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
-    const uint32_t n_path = w.counters[WF_CTR_N_P], n_paths = n_path + w.counters[WF_CTR_N_S];
-    if (blockIdx.x * (uint32_t)kBlock >= n_paths) return;
-    const uint32_t q = blockIdx.x * (uint32_t)kBlock + threadIdx.x;
-    bool have = q < n_paths;             // lanes past the end stay for the wave-wide tally
+    const uint32_t n_pblocks = w.counters[WF_CTR_RAY_P_CHUNKS];
+    if (blockIdx.x >= w.counters[WF_CTR_RAY_CHUNKS]) return;
+    const bool from_shadow = blockIdx.x >= n_pblocks;
+    const uint32_t blk = from_shadow ? blockIdx.x - n_pblocks : blockIdx.x;
+    const uint32_t q = blk * (uint32_t)kBlock + threadIdx.x;
+    bool have = threadIdx.x < block_fill(blk, w.counters + (from_shadow ? WF_CTR_N_S : WF_CTR_N_P));    // lanes past the end stay for the wave-wide tally
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     Path P;
     SampleId id = {0, 0, 0, 0u, 0u};
     P.state = ST_DONE;
     if (have) {
-        if (q < n_path) load_path(w.Pc, q, w, P, id);
+        if (!from_shadow) load_path(w.Pc, q, w, P, id);
         else {
-            load_shadow(w.Sc, q - n_path, w, P, id);
+            load_shadow(w.Sc, q, w, P, id);
             // a record without a pending ray already went through the bsdf stage: its sample lives on elsewhere
-            if (__float_as_int(w.Sc.sd[q - n_path].w) == 0) have = false;
+            if (__float_as_int(w.Sc.sd[q].w) == 0) have = false;
         }
     }
     if (have) {
@@ -1097,8 +1196,15 @@ __global__ __launch_bounds__(kBlock) void wf_pack_rays_kernel(const pt_ray* __re
                                                               uint32_t* __restrict__ counters)
 {
     int i = blockIdx.x * kBlock + threadIdx.x;      // the grid covers n rounded up to whole blocks
+    if (i < kStripes) {
+        // positions 0 .. n-1 in a row, seen as stripes: stripe r holds the blocks r, r + kStripes, ... below n / 256,
+        // and the stripe of block n / 256 the remainder
+        const uint32_t full = (uint32_t)n >> 8, r = (uint32_t)i;
+        const uint32_t mine = full > r ? ((full - r - 1u) >> kStripeShift) + 1u : 0u;
+        counters[WF_CTR_N_P + i] = 0;
+        counters[WF_CTR_N_S + i] = (mine << 8) + ((full & (uint32_t)(kStripes - 1)) == r ? (uint32_t)n & 255u : 0u);
+    }
     if (i == 0) {
-        counters[WF_CTR_N_P] = 0; counters[WF_CTR_N_S] = (uint32_t)n;
         counters[WF_CTR_RAY_NEXT] = 0;
         counters[WF_CTR_RAY_P_CHUNKS] = 0; counters[WF_CTR_RAY_CHUNKS] = (uint32_t)((n + kBlock - 1) / kBlock);
     }
@@ -1232,8 +1338,9 @@ void launch_wf_flush_leftover(const WfParams& w, const DCamera& cam, DCounters* 
 void launch_wf_drain(const WfParams& w, const DScene& S, const DCamera& cam, int max_paths, DCounters* ctr, hipStream_t s)
 {
     hipLaunchKernelGGL(wf_plan_kernel, dim3(1), dim3(kBlock), 0, s, w.counters, (const uint32_t*)w.wg_chunk, w.stage_blocks, w.n_samples, S.sky_mode == PT_SKY_SUNSKY ? 1 : 0);
-    int max_blocks = (max_paths + kBlock - 1) / kBlock;
-    if (max_blocks < 1) max_blocks = 1;
+    // blocks of both queues at most: a stripe's blocks are kStripes apart, and in the worst case one stripe of each
+    // queue holds every record
+    int max_blocks = (max_paths / kBlock + 2) * kStripes;
     if (ctr && w.count_wide && S.wide) hipLaunchKernelGGL((wf_drain_kernel<true, true>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, ctr);
     else if (ctr) hipLaunchKernelGGL((wf_drain_kernel<true, false>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, ctr);
     else if (S.wide) hipLaunchKernelGGL((wf_drain_kernel<false, true>), dim3(max_blocks), dim3(kBlock), 0, s, w, S, cam, ctr);

@@ -181,7 +181,7 @@ int pt_set_env_guides(pt_ctx* ctx, int on, int* verified_out);           /* on (
 
 /* ---- headless rendering (replaces the window loop, main.cpp:247-296) ---- */
 int pt_set_mode(pt_ctx* ctx, int mode);                                 /* PT_MODE_*; both modes give identical accumulators */
-int pt_set_pool(pt_ctx* ctx, int slots, int chunk_frames);              /* wavefront pool size (samples in flight, default 16777216) and frames per staging chunk (default 512; one float per pixel and frame of a chunk is held, and each chunk pays one ramp-up and run-down of the pool) */
+int pt_set_pool(pt_ctx* ctx, int slots, int chunk_frames);              /* wavefront pool size (samples in flight, default 33554432: 17 GB of queue arrays) and frames per staging chunk (default 512; one float per pixel and frame of a chunk is held, and each chunk pays one ramp-up and run-down of the pool) */
 int pt_set_drain(pt_ctx* ctx, int max_rays);                            /* wavefront mode: once every sample is started and at most max_rays paths remain, finish them in one kernel (0 = never) */
 int pt_wavefront_stats(pt_ctx* ctx, uint64_t* iterations_out, uint64_t* drains_out); /* wavefront mode: stage-kernel iterations issued and drain kernels run since the context was created (either pointer may be null) */
 int pt_set_lanes(pt_ctx* ctx, int lanes);                                /* wavefront mode: number of concurrent lanes (streams), each with a share of the pool and of the pixels; default: 2 for renders of three million samples or more, else 1; same accumulator bits */
