@@ -454,17 +454,38 @@ __global__ __launch_bounds__(kBlock) void wf_plan_kernel(uint32_t* __restrict__ 
 #ifndef PT_STAMPS
 #define PT_STAMPS 0      // diagnostic build: pass statistics of the extend kernel
 #endif
+#ifndef PT_TWO_RAYS
+#define PT_TWO_RAYS 0    // the 4-wide walk carries two rays per lane (see wf_extend_kernel)
+#endif
+#ifndef PT_EXTEND_LDS2
+#define PT_EXTEND_LDS2 8
+#endif
 constexpr int kRayChunk = 256;
-constexpr int kExtendLds = 16;          // stack entries per lane in LDS: 16 x 256 lanes x 8 B = 32 KB per workgroup, 5 workgroups per CU
+#ifndef PT_EXTEND_LDS
+#define PT_EXTEND_LDS 14
+#endif
+// Stack entries per lane in LDS: 14 x 256 lanes x 8 B = 28 KB per workgroup. With 16 the workgroup's other shared words
+// made it 32 KB + 128 B: four workgroups per CU instead of the five its registers allow, and no room for a workgroup
+// of the other lane's traversal launch beside them (16 -> 15, 12 or 8: +3 % on the bench, the same for all three).
+constexpr int kExtendLds = PT_EXTEND_LDS;
+constexpr int kExtendLds2 = PT_EXTEND_LDS2;     // ... per ray when a lane carries two
 
 template <bool COUNT, bool WIDE>
 __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S, DCounters* ctr)
 {
-    __shared__ uint2 s_stack[kExtendLds * kBlock];
-    uint2 spill[kSpillDepth];
+    constexpr bool TWO = PT_TWO_RAYS && WIDE;
+    constexpr int LDSE = TWO ? kExtendLds2 : kExtendLds;        // stack entries per ray in LDS
+    __shared__ uint2 s_stack[(TWO ? 2 : 1) * LDSE * kBlock];
+    uint2 spill[(TWO ? 2 : 1) * kSpillDepth];
     const int tid = (int)threadIdx.x;
     const int lane = tid & 63;
     int cur = PT_TRAV_EMPTY, sp = 0;
+    // TWO: the lane's second ray, set aside while the first one is worked on (pcur == PT_TRAV_EMPTY: none), and the
+    // half of the lane's stack space the ray in hand uses
+    int pcur = PT_TRAV_EMPTY, psp = 0, bank = 0;
+    uint32_t pslot = 0;
+    F3 po = f3(0.f, 0.f, 0.f), pd = po, pinv = po;
+    Hit pbest; pbest.t = 1e10f; pbest.tri = PT_NO_TRI; pbest.u = 0.f; pbest.v = 0.f;
     uint32_t slot = 0;
     F3 o = f3(0.f, 0.f, 0.f), d = o, inv = o;
     // ray in grid coordinates for the binary compact nodes
@@ -488,17 +509,17 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
 
     auto push = [&](int ref, float tn) {
         uint2 e = make_uint2((uint32_t)ref, __float_as_uint(tn));
-        if (sp < kExtendLds) s_stack[sp * kBlock + tid] = e;
-        else if (sp - kExtendLds < kSpillDepth) spill[sp - kExtendLds] = e;
+        if (sp < LDSE) s_stack[(bank * LDSE + sp) * kBlock + tid] = e;
+        else if (sp - LDSE < kSpillDepth) spill[bank * kSpillDepth + sp - LDSE] = e;
         sp++;
     };
     auto pop_valid = [&]() -> int {
         while (sp > 0) {
             sp--;
             uint2 e;
-            if (sp < kExtendLds) e = s_stack[sp * kBlock + tid];
+            if (sp < LDSE) e = s_stack[(bank * LDSE + sp) * kBlock + tid];
             else {
-                e = spill[(sp - kExtendLds) < kSpillDepth ? (sp - kExtendLds) : (kSpillDepth - 1)];
+                e = spill[bank * kSpillDepth + ((sp - LDSE) < kSpillDepth ? (sp - LDSE) : (kSpillDepth - 1))];
                 asm volatile("" : "+v"(e.x), "+v"(e.y));    // keep the LDS and the private load apart
             }
             if (__uint_as_float(e.y) < (WIDE ? wide_cull(best.t) : best.t)) return (int)e.x;
@@ -517,25 +538,54 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     };
 
     for (;;) {
-        // ---- decide what this pass does. Every lane is in exactly one state: idle, descending (cur is an
-        // interior node) or waiting at a leaf.
-        const bool idle = !has_ray;
+        // ---- decide what this pass does. A ray is descending (cur is an interior node) or waiting at a leaf.
+        // TWO: a lane carries up to two rays and works on the one that fits the pass: while one waits for the wave's
+        // next leaf pass the other descends, so fewer lanes sit out a pass (a ray's hit does not depend on when its
+        // steps are taken). The ray set aside keeps its registers; the two change places only when the lane has
+        // nothing to do for the one in hand.
+        bool leaf_on = false;
+        unsigned long long none_mask = 0ull;
+        if constexpr (TWO) {
+            const bool p_none = pcur == PT_TRAV_EMPTY, p_node = pcur >= 0, p_leaf = !p_none && pcur < 0;
+            const bool a_node = has_ray && cur >= 0, a_leaf = has_ray && cur < 0;
+            const bool any_node = a_node || p_node, any_leaf = a_leaf || p_leaf;
+            none_mask = __ballot(!has_ray && p_none);
+            const int n_act = 64 - __popcll(none_mask);
+            const int need = (n_act >> 1) < w.leaf_vote ? ((n_act >> 1) > 1 ? (n_act >> 1) : 1) : w.leaf_vote;
+            // a leaf pass when enough lanes have only leaf work left, or nobody can descend
+            leaf_on = __popcll(__ballot(any_leaf && !any_node)) >= need || __ballot(any_node) == 0ull;
+            const bool change = leaf_on ? (!a_leaf && p_leaf) : (!a_node && p_node);
+            if (change) {
+                // (one exchange instruction per register: written out as three moves each, the compiler also copied the
+                // whole state at both ends of the loop)
+#define PT_SWAP(a, b) asm volatile("v_swap_b32 %0, %1" : "+v"(a), "+v"(b))
+                PT_SWAP(cur, pcur); PT_SWAP(sp, psp); PT_SWAP(slot, pslot);
+                PT_SWAP(o.x, po.x); PT_SWAP(o.y, po.y); PT_SWAP(o.z, po.z);
+                PT_SWAP(d.x, pd.x); PT_SWAP(d.y, pd.y); PT_SWAP(d.z, pd.z);
+                PT_SWAP(inv.x, pinv.x); PT_SWAP(inv.y, pinv.y); PT_SWAP(inv.z, pinv.z);
+                PT_SWAP(best.t, pbest.t); PT_SWAP(best.tri, pbest.tri); PT_SWAP(best.u, pbest.u); PT_SWAP(best.v, pbest.v);
+#undef PT_SWAP
+                bank ^= 1;
+                has_ray = cur != PT_TRAV_EMPTY;
+            }
+        }
+        const bool idle = TWO ? (!has_ray || pcur == PT_TRAV_EMPTY) : !has_ray;      // the lane can take a new ray
         const bool descending = has_ray && cur >= 0;
         const bool at_leaf = has_ray && cur < 0;
         const unsigned long long idle_mask = __ballot(idle);
         const unsigned long long desc_mask = __ballot(descending);
         const unsigned long long leaf_mask = __ballot(at_leaf);
         const int n_idle = __popcll(idle_mask);
-        if (n_idle == 64 && !more) break;
+        if (!more && (TWO ? none_mask == ~0ull : n_idle == 64)) break;
         const bool do_refill = more && n_idle >= w.refill_lanes;
         // the vote is taken among the lanes that carry a ray: a wave that is running out of rays must not wait for
         // sixteen of them at leaves
         const int n_active = 64 - n_idle;
         const int vote_need = (n_active >> 1) < w.leaf_vote ? ((n_active >> 1) > 1 ? (n_active >> 1) : 1) : w.leaf_vote;
-        const bool leaf_now = at_leaf && (__popcll(leaf_mask) >= vote_need || desc_mask == 0ull);
+        const bool leaf_now = TWO ? (at_leaf && leaf_on) : (at_leaf && (__popcll(leaf_mask) >= vote_need || desc_mask == 0ull));
 #if PT_STAMPS
         st_age++; st_iters++; st_lanes += __popcll(desc_mask); st_leafphases += __any(leaf_now) ? 1 : 0; st_refills += do_refill ? 1 : 0;
-        st_leaflanes += __popcll(__ballot(leaf_now)); st_idle += n_idle;
+        st_leaflanes += __popcll(__ballot(leaf_now)); st_idle += __popcll(__ballot(!descending && !leaf_now));
         if (!more) { if (!st_tail) st_tail_t0 = __builtin_amdgcn_s_memtime(); st_tail++; st_tail_idle += n_idle; st_tail_desc += __popcll(desc_mask); }
 #endif
         // ---- issue every load of the pass before anything waits: a pass then costs one memory latency,
@@ -695,33 +745,44 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         }
         // ---- new rays for the lanes that were idle
         if (got && (!chunk_shadow || __float_as_int(rd4.w) != 0)) {
-            slot = idx | (chunk_shadow ? 0x80000000u : 0u);
-            o = f3(ro4.x, ro4.y, ro4.z); d = f3(rd4.x, rd4.y, rd4.z);
-            best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
-            sp = 0;
-#if PT_STAMPS
-            st_age = 0;
-#endif
-            has_ray = true;
+            const uint32_t nslot = idx | (chunk_shadow ? 0x80000000u : 0u);
+            const F3 no = f3(ro4.x, ro4.y, ro4.z), nd = f3(rd4.x, rd4.y, rd4.z);
+            F3 ninv = f3(0.f, 0.f, 0.f);
             if (COUNT) { tl.rays++; if (!chunk_shadow) tl.path_rays++; }
-            cur = PT_TRAV_EMPTY;
-            if (finite3(o) && finite3(d)) {
+            int ncur = PT_TRAV_EMPTY;
+            if (finite3(no) && finite3(nd)) {
                 // the quantized boxes carry two cells of padding (the root box 0.1 units): the hardware reciprocal's
                 // last-bit error cannot lose a box, and saves three IEEE divisions per ray
-                if (WIDE) inv = wide_inv(d);
-                else if (QUANT) inv = f3(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-                else inv = 1.0f / d;
+                if (WIDE) ninv = wide_inv(nd);
+                else if (QUANT) ninv = f3(__builtin_amdgcn_rcpf(nd.x), __builtin_amdgcn_rcpf(nd.y), __builtin_amdgcn_rcpf(nd.z));
+                else ninv = 1.0f / nd;
                 if (COUNT && !WIDE) tl.box += 1;
 #if PT_SKIP_ROOT_TEST
                 // the 4-wide walk starts at the root node without testing the scene box: the root's child boxes cull
                 // a ray that misses the scene in one step, and nearly every ray of a render starts inside it
-                if (WIDE && S.root_ref4 >= 0) cur = S.root_ref4;
+                if (WIDE && S.root_ref4 >= 0) ncur = S.root_ref4;
                 else
 #endif
                 {
-                    float troot = box_entry(o, inv, S.root_min, S.root_max);
-                    if (troot < best.t) cur = WIDE ? S.root_ref4 : S.root_ref;
+                    float troot = box_entry(no, ninv, S.root_min, S.root_max);
+                    if (troot < 1e10f) ncur = WIDE ? S.root_ref4 : S.root_ref;
                 }
+            }
+            if (ncur == PT_TRAV_EMPTY) {
+                // nothing to walk: the ray's record says so at once
+                ((nslot >> 31) ? w.hitS : w.hitP)[nslot & 0x7FFFFFFFu] = make_float4(1e10f, __uint_as_float(PT_NO_TRI), 0.f, 0.f);
+            } else if (TWO && has_ray) {
+                pslot = nslot; po = no; pd = nd; pinv = ninv;
+                pbest.t = 1e10f; pbest.tri = PT_NO_TRI; pbest.u = 0.f; pbest.v = 0.f;
+                psp = 0; pcur = ncur;
+            } else {
+                slot = nslot; o = no; d = nd; inv = ninv;
+                best.t = 1e10f; best.tri = PT_NO_TRI; best.u = 0.f; best.v = 0.f;
+                sp = 0; cur = ncur;
+#if PT_STAMPS
+                st_age = 0;
+#endif
+                has_ray = true;
                 if (QUANT && !WIDE) {
                     oq = (o - ld3(S.q_origin)) * ld3(S.q_inv_cell);
                     invq = inv * ld3(S.q_cell);
@@ -733,7 +794,6 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                     noq = f3(-(oq.x * invq.x), -(oq.y * invq.y), -(oq.z * invq.z));
                 }
             }
-            if (cur == PT_TRAV_EMPTY) retire();
         }
     }
 #if PT_STAMPS
