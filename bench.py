@@ -192,7 +192,7 @@ def main():
     r.set_max_bounces(args.bounces)
     r.set_mode(0 if args.mode == 'wavefront' else 1)
     if args.pool or args.chunk_frames:
-        r.set_pool(args.pool or (1 << 25), args.chunk_frames or 512)
+        r.set_pool(args.pool or (1 << 27), args.chunk_frames or 512)
     if args.node_width != 4 or args.leaf_merge != 2:
         r.set_node_width(args.node_width, args.leaf_merge)
         if bundle is not None:
@@ -265,8 +265,8 @@ def main():
         elapsed = float(t.item())
 
     # untimed: the last timed step once more with HIP events around every stage kernel (on the launch streams), in the
-    # timed configuration (two lanes: a lane's kernels run beside the other's and are stretched by the sharing) and on
-    # one lane, where a step's kernel times add up
+    # timed configuration and on one lane, where a step's kernel times add up (the same thing unless --lanes 2 makes the
+    # kernels of two lanes share the GPU)
     stage = {}
     if args.mode == 'wavefront':
         for tag in ('timed_config', 'one_lane'):
@@ -278,7 +278,7 @@ def main():
             ms, iters = r.stage_times()
             r.stage_timing(False)
             stage[tag] = (ms, max(iters, 1))
-        r.set_lanes(args.lanes or 2)
+        r.set_lanes(args.lanes or 1)
     # untimed: count rays and tests of exactly the timed frames with the instrumented kernels, twice: the
     # reference-order binary walk (its box and triangle tests are the reference's own) and the production walk
     # over the wide nodes (the node visits and triangle tests the timed kernel really made)
@@ -394,7 +394,7 @@ def main():
                                             'note': 'the layout-independent accounting (40 + 32 per box test + 48 per triangle test of the reference\'s binary walk); above 1 it only says that the timed kernel does not do that work: its 4-wide walk visits a fifth as many nodes'},
                          'issue': ({'valu_busy': valu, 'valu_lanes_per_instruction': ext.get('valu_lanes_per_instruction'), 'wave_wait_share': ext.get('wave_wait_share')} if valu is not None else None),
                          'kernels': kernels,
-                         'kernels_note': 'ms_per_step: HIP events around every launch of one untimed step on one lane (the times add up to the step); ms_per_step_timed_config: the same in the timed configuration, where the kernels of two lanes share the GPU; requested bytes from the record layouts and the tallies of the instrumented run; pmc_*, valu_*, wave_wait_share, waves_per_simd from the committed rocprofv3 counter passes (profiles/pmc_traffic.json), null when none matches this workload and size',
+                         'kernels_note': 'ms_per_step: HIP events around every launch of one untimed step on one lane (the times add up to the step); ms_per_step_timed_config: the same in the timed configuration (it differs only under --lanes 2, where the kernels of two lanes share the GPU); requested bytes from the record layouts and the tallies of the instrumented run; pmc_*, valu_*, wave_wait_share, waves_per_simd from the committed rocprofv3 counter passes (profiles/pmc_traffic.json), null when none matches this workload and size',
                          'whole_path_algorithmic_GBs': round(algorithmic_bytes(loc) / (elapsed * 1e9), 2)},
         }
 

@@ -120,13 +120,18 @@ struct pt_ctx {
     size_t n_nodes = 0, n_nodes4 = 0;
     // wavefront pool
     int mode = PT_MODE_WAVEFRONT;
-    int pool_slots = 1 << 25;      // (2^24: +3 % time on the bench, 2^26: -0.5 %; 520 bytes of queue arrays per slot)
+    // Samples in flight at most: 520 bytes of queue arrays each, allocated for what a render needs (never more than its
+    // samples). 2^27 holds a whole 64-spp 1080p chunk (70 GB of the 288): no sample waits for a slot, and the stage
+    // loop takes 28 iterations instead of 38. Bench: 2^24 -6 %, 2^25 -4.4 %, 2^26 -2.6 %.
+    int pool_slots = 1 << 27;
     int chunk_frames = 512;         // frames per staging chunk: every chunk pays one ramp-up and one run-down of the pool
     int refill_lanes = 8, leaf_vote = 24, n_cus = 256;
-    int extend_blocks_per_cu = 0;   // 0: 5 when one lane runs (all the LDS), 3 when two do
-    // The wavefront loop runs as up to two independent lanes, each with its own slot pool, staging array,
+    int extend_blocks_per_cu = 0;   // 0: 5 when one lane runs (what its registers allow), 4 when two do
+    // The wavefront loop can run as two independent lanes, each with its own slot pool, staging array,
     // counters and stream, on disjoint pixels (alternate blocks of 64): while one lane's traversal kernel (ALU bound)
-    // runs, the other lane's shading kernels (memory bound) can share the GPU.
+    // runs, the other lane's shading kernels (memory bound) can share the GPU. One lane is the default: since the
+    // traversal kernel fits five workgroups per CU it fills the chip alone, and two lanes are 1-2 % slower on the
+    // bench scenes (pt_set_lanes selects two).
     struct WfLane {
         hipStream_t stream = nullptr;   // lane 0 runs on the context's stream, the others on their own
         void* block = nullptr;          // one allocation holding every slot array
@@ -149,7 +154,7 @@ struct pt_ctx {
     };
     static constexpr int kMaxLanes = 2;
     WfLane lanes[kMaxLanes];
-    int n_lanes = 2;
+    int n_lanes = 1;
     bool lanes_forced = false;      // pt_set_lanes was called: use that count whatever the render size
     hipEvent_t ev_fork = nullptr;
     // pt_render_frame renders a few frames ahead into the staging arrays while the caller keeps asking for the next

@@ -46,6 +46,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 
+
 // flags word: state[1:0] ch[3:2] inside[4] surface_scatter[5] sh_inside[6] nee_surface[7] nee_skip[8] v_inside[9] seg[15:10] lobes[19:16] bounce[31:20]
 PT_DEV uint32_t pack_flags(const Path& P)
 {
@@ -621,7 +622,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
             // a path record's ray is its (o, d); a shadow record's the pending segment of its visibility walk
             if (got) { rd4 = (chunk_shadow ? w.Sc.sd : w.Pc.c1)[idx]; ro4 = (chunk_shadow ? w.Sc.so : w.Pc.c0)[idx]; }
         }
-        float4 n0 = ro4, n1 = ro4, n2 = ro4, n3 = ro4;
+        float4 n0, n1, n2, n3;          // (read only by the lanes that load them: no defined value elsewhere, so no copies)
         if (descending) {
             if (WIDE) {
                 const float4* np = reinterpret_cast<const float4*>(S.nodes4 + cur);
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
                 n0 = np[0]; n1 = np[1]; n2 = np[2]; n3 = np[3];
             }
         }
-        float4 q0 = ro4, q1 = ro4, q2 = ro4, p0 = ro4, p1 = ro4, p2 = ro4;
+        float4 q0, q1, q2, p0, p1, p2;
         const DTri* tp = S.tris;
         int leaf_count = 0;
         if (leaf_now) {

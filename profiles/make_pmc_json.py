@@ -42,7 +42,7 @@ def avg_ns(path, kernel):
 
 
 def kernel_table(d, prefix, suffix, names):
-    """suffix '': the passes in the bench's default configuration (two lanes); '1': the passes on one lane."""
+    """suffix '': the passes in the bench's default configuration; '1': the passes with one lane forced."""
     kernels = {}
     for k in names:
         sq = counters(os.path.join(d, prefix + 'sq' + suffix + '.txt'), k)
@@ -78,10 +78,10 @@ def entry(d, prefix, workload, tag, scene_note):
         'workload': workload,
         'kernels': kernel_table(d, prefix, '1', KERNELS),
         'extend_timed_config': kernel_table(d, prefix, '', ['wf_extend_kernel']).get('wf_extend_kernel'),
-        'note': 'kernels: one lane, where a launch covers the whole pool and runs alone; extend_timed_config: the traversal kernel in the bench\'s default configuration (two lanes, '
-                'each launch covers half the pool; its mean launch time is that of the two-lane kernel trace, %s_%sstats.txt, stretched by the other lane\'s kernels). '
+        'note': 'kernels: one lane forced, where a launch covers the whole pool and runs alone; extend_timed_config: the traversal kernel in the bench\'s default configuration (one '
+                'lane as well, since that became the default; its mean launch time is that of the default kernel trace, %s_%sstats.txt). '
                 'Per launch of the uncounted kernels. pmc_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024 from separate --pmc passes (counter collection '
-                'serialises the two lanes); gfx950 tallies a 128-byte read request at 64 bytes, which halves coalesced full-line reads but not random reads of 64-byte '
+                'serialises concurrent kernels); gfx950 tallies a 128-byte read request at 64 bytes, which halves coalesced full-line reads but not random reads of 64-byte '
                 'records (profiles/r2_fetch_size_calibration.txt), so the truth lies between pmc_bytes and pmc_bytes_upper_bound (2 * FETCH_SIZE + WRITE_SIZE): near the lower '
                 'figure for the traversal kernel (random node reads), near the upper one for the stage kernels (streams over the queue arrays). Fractions of the HBM peak use the '
                 'mean launch time of the one-lane kernel trace (%s_%sstats1.txt). valu_busy = SQ_ACTIVE_INST_VALU*4/1024/(GRBM_GUI_ACTIVE/8) (share of the 1024 SIMD issue slots '

@@ -1,6 +1,2 @@
 #!/bin/bash
-# A/B of LDS stack depths of the traversal kernel (workgroups per CU that fit) against the default build.
-for b in 4 5; do
-echo "two lanes, blocks $b"; bash tools/ab.sh "--tune 8,24,$b" base lds15 lds12 lds8 || exit 1
-done
-echo "one lane, blocks 5"; bash tools/ab.sh "--lanes 1 --tune 8,24,5" base lds15 lds12 lds8 || exit 1
+for a in "--lanes 1 --pool 33554432" "--lanes 1 --pool 67108864" "--lanes 1 --pool 134217728" "--lanes 2 --pool 67108864" "--lanes 2 --pool 134217728" "--lanes 1 --pool 50331648"; do echo -n "$a  "; bash tools/ab.sh "$a" x | sed 's/^x: //' || exit 1; done
