@@ -866,7 +866,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RESOL
 // queue: medium event, alpha test, light-sample set-up. A vertex that drew a light sample completes its record
 // where it is; a ray that passed through the surface moves on to the next path queue and leaves a dead record.
 #ifndef PT_VERTEX_WAVES
-#define PT_VERTEX_WAVES 5       // (4: -1.2 % on the bench; 6 spills: -3.5 %)
+#define PT_VERTEX_WAVES 4       // (5 spills 24 registers, 250 in the sun/sky variant: -1.5 % on the bench, -14 % on the sun/sky scene; 3: the same as 4)
 #endif
 // DIRECT: for scenes that draw no light samples (sun/sky mode). The vertex has no visibility walk to wait for, so
 // its bsdf stage (after_light) runs here, on the state in registers, instead of going through a shadow-queue record.
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(kBlock) void wf_miss_kernel(WfParams w, DScene S, D
 // position goes onto the bsdf list, ordered within the workgroup by the kind of work the bsdf stage will do
 // for it; a walk that goes on (it passed an alpha cut-out or an index-matched surface) moves to the next shadow queue.
 #ifndef PT_SHADOW_WAVES
-#define PT_SHADOW_WAVES 6
+#define PT_SHADOW_WAVES 8       // 71 registers: no spill at 8 (6: -1 % on the bench)
 #endif
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADOW_WAVES))) void wf_shadow_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
 // Everything after the light sample of a vertex (pathtracer.cu:318-338, :449-451 or :471-480, :484-490) for the
 // records on the bsdf list.
 #ifndef PT_BSDF_WAVES
-#define PT_BSDF_WAVES 4
+#define PT_BSDF_WAVES 3         // (4 spills 38 registers: -0.5 %; 5: -6 %)
 #endif
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_BSDF_WAVES))) void wf_bsdf_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)

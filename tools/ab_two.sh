@@ -1,2 +1,4 @@
 #!/bin/bash
-for a in "--lanes 1 --pool 33554432" "--lanes 1 --pool 67108864" "--lanes 1 --pool 134217728" "--lanes 2 --pool 67108864" "--lanes 2 --pool 134217728" "--lanes 1 --pool 50331648"; do echo -n "$a  "; bash tools/ab.sh "$a" x | sed 's/^x: //' || exit 1; done
+bash tools/ab.sh "" c2 d1 d2 d3 c2 d1 d2 d3
+bash tools/ab.sh "--workload sunsky" base c2 d1
+bash tools/ab.sh "--workload soup --spp 16" base c2 d1
