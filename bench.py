@@ -33,6 +33,8 @@ sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 import numpy as np  # noqa: E402
 
+N_SIMDS, CLOCK_GHZ = 1024, 2.4      # 256 CUs x 4 SIMDs; one wave64 vector instruction per SIMD every 4 cycles
+VALU_PEAK_GINST = N_SIMDS * CLOCK_GHZ / 4
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E datasheet peak
 STAGES = ('extend', 'resolve', 'vertex', 'miss', 'shadow', 'bsdf')
 KERNEL_NAMES = {'extend': 'wf_extend_kernel', 'resolve': 'wf_resolve_kernel', 'vertex': 'wf_vertex_kernel', 'miss': 'wf_miss_kernel',
@@ -353,17 +355,29 @@ def main():
             launches = args.steps
             kms = float(np.mean(kernel_ms))
             alg_per_launch = ref_per_launch = own_per_launch = algorithmic_bytes(loc) / args.steps
-        achieved = alg_per_launch / (kms * 1e-3) / 1e9
+        requested_gbs = alg_per_launch / (kms * 1e-3) / 1e9
         ext = pm.get('extend_timed_config') or {}
         traffic = ext.get('pmc_bytes_per_launch')
         traffic_frac = round(traffic / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if traffic else None
         # What bounds the kernel, from the counters: memory when what reaches HBM is the larger share of its ceiling, else
         # vector instruction issue (the scene is cache resident then and the requested bytes are a gather rate, not HBM use).
+        # achieved / peak / frac are stated against that bound: bytes that reached the memory side per second against
+        # the HBM peak, or vector instructions issued per second (the instruction count of a launch from the committed
+        # counter pass over the same workload, the launch time measured here) against one instruction per SIMD every
+        # four cycles.
         valu = ext.get('valu_busy')
-        if traffic_frac is None or valu is None:
+        insts = ext.get('valu_instructions_per_launch')
+        if traffic_frac is None or valu is None or not insts:
             bound = 'unmeasured (no counters committed for this workload and size; achieved is requested bytes over time)'
+            achieved, peak, unit, frac_of = requested_gbs, HBM_PEAK_GBS, 'GB/s', 'bytes the kernel requests / launch time / HBM peak: a gather rate, served mostly by the caches when the scene fits them'
+        elif traffic_frac >= valu:
+            bound = 'hbm'
+            achieved, peak, unit, frac_of = traffic / (kms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s', 'PMC bytes that reached the memory side (FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json) / launch time / HBM peak'
         else:
-            bound = 'hbm' if traffic_frac >= valu else 'valu_issue'
+            bound = 'valu_issue'
+            achieved, peak, unit = insts / (kms * 1e-3) / 1e9, VALU_PEAK_GINST, 'Ginst/s'
+            frac_of = ('vector instructions of a launch (SQ_INSTS_VALU of the committed counter pass) / launch time measured here / (%d SIMDs x %.1f GHz / 4 cycles per wave64 instruction); '
+                       'the same pass puts the vector ALUs at valu_busy of their cycles with valu_lanes_per_instruction of the lanes active' % (N_SIMDS, CLOCK_GHZ))
         ref_frac = ref_per_launch / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS
         result = {
             'metric': 'Mrays/s', 'value': round(mrays, 3), 'unit': 'Mrays/s',
@@ -379,11 +393,12 @@ def main():
                                      ('samples: rank r renders frames [k*S + r*S/N, k*S + (r+1)*S/N) of step k, RCCL reduce to rank 0' if strong else
                                       'samples: rank r renders frames [(k*N+r)*spp, +spp), RCCL reduce to rank 0')),
                        'scene_bytes': {'nodes': node_b, 'triangles': tri_b}},
-            'roofline': {'bound': bound, 'kernel': kname, 'launches': int(launches), 'achieved': round(achieved, 2), 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': round(achieved / HBM_PEAK_GBS, 5),
-                         'frac_of': 'bytes the kernel requests (48 per ray + 64 per wide node visited + 48 per triangle tested) / launch time / HBM peak: a gather rate; most of it is served by L2 and Infinity Cache when the scene fits them',
+            'roofline': {'bound': bound, 'kernel': kname, 'launches': int(launches), 'achieved': round(achieved, 2), 'peak': peak,
+                         'unit': unit, 'frac': round(achieved / peak, 5), 'frac_of': frac_of,
                          'traffic': traffic, 'hbm_traffic_frac': traffic_frac,
                          'hbm_traffic_frac_of': 'PMC bytes that reached the memory side (FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json) / launch time / HBM peak',
+                         'requested': {'GBs': round(requested_gbs, 2), 'over_hbm_peak': round(requested_gbs / HBM_PEAK_GBS, 5),
+                                       'note': 'bytes the kernel asks the memory system for (48 per ray + 64 per wide node visited + 48 per triangle tested) / launch time: a gather rate, served mostly by L2 and Infinity Cache when the scene fits them, so it can exceed the HBM peak'},
                          'kernel_ms': round(kms, 4),
                          'algorithmic_bytes_per_launch': int(alg_per_launch),
                          'own_walk_per_ray': {'wide_nodes': round(loc['wide_nodes'] / max(loc['rays'], 1), 3), 'tri_tests': round(loc['wide_tris'] / max(loc['rays'], 1), 3),

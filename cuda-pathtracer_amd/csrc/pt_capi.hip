@@ -1071,9 +1071,12 @@ static int lane_counters(pt_ctx::WfLane& L)
 
 // Workgroups of a stage launch for a pool of `slots` samples in flight: enough to fill the GPU with the lightest
 // stage kernel, and no more than the pool has 256-record segments.
+#ifndef PT_STAGE_BLOCKS_PER_CU
+#define PT_STAGE_BLOCKS_PER_CU 8
+#endif
 static int stage_blocks_for(const pt_ctx* c, size_t slots)
 {
-    size_t b = (size_t)8 * (size_t)c->n_cus, segs = slots / 256;
+    size_t b = (size_t)PT_STAGE_BLOCKS_PER_CU * (size_t)c->n_cus, segs = slots / 256;
     if (segs < 1) segs = 1;
     return (int)(b < segs ? b : segs);
 }

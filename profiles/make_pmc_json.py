@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Builds profiles/pmc_traffic.json (read by bench.py for the counter-derived fields of its roofline) from the per-kernel
 summaries tools/profile_round.sh leaves: DIR/{sq,fetch,write,stats1}.txt for the atrium at the bench's default size and
-DIR/soup_{sq,fetch,write,stats1}.txt for the 10-million-triangle soup at 16 samples a pixel.
+DIR/soup_{sq,fetch,write,stats1}.txt for the 10-million-triangle soup at 16 samples a pixel, DIR/sunsky_... for the sun/sky
+configuration.
 
 usage: profiles/make_pmc_json.py DIR TAG     (TAG names the committed copies, profiles/TAG_*.txt)
 """
@@ -97,6 +98,8 @@ def main():
                         'The scene (about 30 MB) is served from L2 / Infinity Cache, so the traversal kernel\'s memory-side traffic is far below its requested byte count.'),
         'soup': entry(d, 'soup_', [1920, 1080, 16, 512], tag,
                       'The 0.8 GB of wide nodes and triangle records fit no cache, but the upper levels of the tree do: a little over half of the bytes asked for reach the memory side.'),
+        'sunsky': entry(d, 'sunsky_', [1920, 1080, 64, 16], tag,
+                        'Sun/sky mode draws no light samples: there is no shadow stage, and the bsdf stage runs inside the vertex kernel.'),
     }
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'pmc_traffic.json'), 'w') as f:
         json.dump(out, f, indent=1)
