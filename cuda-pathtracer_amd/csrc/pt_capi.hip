@@ -1259,8 +1259,8 @@ static int render_wavefront_chunks(pt_ctx* c, const DCamera& cam, int f0, int f1
     size_t pixel_blocks = (npix + 63) / 64;
     for (int b = f0; b < f1; b += max_chunk) {
         int frames = (f1 - b) < max_chunk ? (f1 - b) : max_chunk;
-        // a second lane pays from about three million samples on (measured: a 1080p frame is faster on one lane,
-        // two frames on two); the split never changes a result, so small renders may use any count
+        // two lanes, when asked for through the default count, only from about three million samples on (a 1080p
+        // frame is faster on one lane); the split never changes a result, so small renders may use any count
         int n_lanes = (size_t)c->n_lanes < pixel_blocks ? c->n_lanes : (int)pixel_blocks;
         if (!c->lanes_forced && npix * (size_t)frames < ((size_t)3 << 20)) n_lanes = 1;
         size_t lane_pool_slots = (size_t)c->pool_slots / (size_t)n_lanes;

@@ -36,7 +36,7 @@ extern "C" {
 #define PT_SKY_SUNSKY    1
 
 /* how pt_render_headless / pt_render_frame schedule the work */
-#define PT_MODE_WAVEFRONT     0   /* stage kernels over a pool of path slots (default) */
+#define PT_MODE_WAVEFRONT     0   /* stage kernels over dense queues of samples in flight (default) */
 #define PT_MODE_SINGLE_KERNEL 1   /* one kernel, one pixel per lane, as pathtracer.cu:544-606 launches it */
 
 /* BVH build flavours for pt_host_build_bvh / pt_build_bvh */
@@ -181,10 +181,10 @@ int pt_set_env_guides(pt_ctx* ctx, int on, int* verified_out);           /* on (
 
 /* ---- headless rendering (replaces the window loop, main.cpp:247-296) ---- */
 int pt_set_mode(pt_ctx* ctx, int mode);                                 /* PT_MODE_*; both modes give identical accumulators */
-int pt_set_pool(pt_ctx* ctx, int slots, int chunk_frames);              /* wavefront pool size (samples in flight, default 33554432: 17 GB of queue arrays) and frames per staging chunk (default 512; one float per pixel and frame of a chunk is held, and each chunk pays one ramp-up and run-down of the pool) */
+int pt_set_pool(pt_ctx* ctx, int slots, int chunk_frames);              /* samples in flight at most (default 134217728 = 2^27: 520 bytes of queue arrays each, allocated for what a render needs and never for more than its samples; a 64-spp 1080p render holds 70 GB) and frames per staging chunk (default 512; one float per pixel and frame of a chunk is held, and each chunk pays one ramp-up and run-down of the queues) */
 int pt_set_drain(pt_ctx* ctx, int max_rays);                            /* wavefront mode: once every sample is started and at most max_rays paths remain, finish them in one kernel (0 = never) */
 int pt_wavefront_stats(pt_ctx* ctx, uint64_t* iterations_out, uint64_t* drains_out); /* wavefront mode: stage-kernel iterations issued and drain kernels run since the context was created (either pointer may be null) */
-int pt_set_lanes(pt_ctx* ctx, int lanes);                                /* wavefront mode: number of concurrent lanes (streams), each with a share of the pool and of the pixels; default: 2 for renders of three million samples or more, else 1; same accumulator bits */
+int pt_set_lanes(pt_ctx* ctx, int lanes);                                /* wavefront mode: number of concurrent lanes (streams), each with a share of the samples in flight and of the pixels: 1 (default) or 2; same accumulator bits */
 int pt_set_extend_tuning(pt_ctx* ctx, int refill_lanes, int leaf_vote, int blocks_per_cu); /* traversal kernel: idle lanes before a refill, lanes waiting at leaves before a leaf pass, resident workgroups per CU */
 int pt_set_node_width(pt_ctx* ctx, int width, int leaf_merge);         /* production traversal: 4-wide (default) or binary compact nodes; subtrees of <= leaf_merge triangles (default 2) become one wide leaf at the next BVH upload; a tree too deep for the 4-wide stack uses binary */
 int pt_set_max_bounces(pt_ctx* ctx, int max_bounces);                   /* pathtracer.cu:405 hard-codes 512 */
