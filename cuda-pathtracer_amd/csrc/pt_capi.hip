@@ -1124,13 +1124,22 @@ static void pool_layout(pt_ctx::WfLane& L, void* base_ptr, size_t capacity, int 
 // Lays the queue arrays of a lane out in its block (grown if needed) for `slots` samples in flight.
 static int lane_pool(pt_ctx* c, pt_ctx::WfLane& L, size_t slots, WfParams* w)
 {
-    const int stage_blocks = stage_blocks_for(c, slots);
-    const size_t capacity = queue_capacity(c, slots);
+    int stage_blocks = stage_blocks_for(c, slots);
+    size_t capacity = queue_capacity(c, slots);
     size_t need = pool_bytes(capacity, stage_blocks);
-    if (need > L.block_bytes) {
+    while (need > L.block_bytes) {
         if (L.block) { (void)hipFree(L.block); L.block = nullptr; L.block_bytes = 0; }
-        HIP_TRY(hipMalloc(&L.block, need));
-        L.block_bytes = need;
+        const hipError_t e = hipMalloc(&L.block, need);
+        if (e == hipSuccess) { L.block_bytes = need; break; }
+        L.block = nullptr;
+        (void)hipGetLastError();
+        // The device does not have that much memory free (the default asks for up to 70 GB): fewer samples in flight
+        // change the number of stage iterations, never a result.
+        if (e != hipErrorOutOfMemory || slots <= ((size_t)1 << 20)) { set_error("hipMalloc of %zu bytes for the sample queues: %s", need, hipGetErrorString(e)); return PT_ERR_HIP; }
+        slots = (slots / 2 + 255) / 256 * 256;
+        stage_blocks = stage_blocks_for(c, slots);
+        capacity = queue_capacity(c, slots);
+        need = pool_bytes(capacity, stage_blocks);
     }
     int rc = lane_counters(L);
     if (rc != PT_OK) return rc;

@@ -208,6 +208,38 @@ def test_wavefront_pool_size_does_not_change_results(pool):
         assert ctr[k] == st[k], k
 
 
+def test_sample_queues_shrink_when_the_device_is_short_of_memory():
+    """The default asks for queue arrays for every sample of a chunk at once (520 bytes each, up to 70 GB). On a
+    device that does not have them free the library halves the samples in flight until the arrays fit: more stage
+    iterations, the same image."""
+    import torch
+    b = util.atrium(detail=0.3)
+    W, H, frames = 1280, 720, 4                       # 3.7 million samples: 1.9 GB of queue arrays
+    P = scenes.atrium_params(ptamd.default_params(W, H))
+    r = b.renderer(P, 0)
+    r.set_max_bounces(6)
+    r.render(P, 0, frames)
+    want = r.read_accum()
+    iters_all = r.wavefront_stats()['iterations']
+    r.close()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    hog = torch.empty(max(free - (1200 << 20), 0), dtype=torch.uint8, device='cuda')      # leave 1.2 GB
+    try:
+        r = b.renderer(P, 0)
+        r.set_max_bounces(6)
+        r.render(P, 0, frames)
+        got = r.read_accum()
+        iters_short = r.wavefront_stats()['iterations']
+        r.close()
+    finally:
+        del hog
+        torch.cuda.empty_cache()
+    assert np.array_equal(bits(got), bits(want))
+    assert iters_short > iters_all                    # the samples went through in several turns
+
+
 def test_render_frame_matches_reference_frame_loop():
     """pt_render_frame == render(): 1 spp per call, frame 0 overwrites, RGBA8 of accum/(frame+1)."""
     b = util.cornell('sky')
