@@ -127,7 +127,7 @@ struct pt_ctx {
     int chunk_frames = 512;         // frames per staging chunk: every chunk pays one ramp-up and one run-down of the pool
     int refill_lanes = 8, leaf_vote = 24, n_cus = 256;
     int extend_blocks_per_cu = 0;   // 0: 5 when one lane runs (what its registers allow), 4 when two do
-    // The wavefront loop can run as two independent lanes, each with its own slot pool, staging array,
+    // The wavefront loop can run as two independent lanes, each with its own sample queues, staging array,
     // counters and stream, on disjoint pixels (alternate blocks of 64): while one lane's traversal kernel (ALU bound)
     // runs, the other lane's shading kernels (memory bound) can share the GPU. One lane is the default: since the
     // traversal kernel fits five workgroups per CU it fills the chip alone, and two lanes are 1-2 % slower on the
@@ -1170,7 +1170,7 @@ static WfParams lane_feed_view(const pt_ctx::WfLane& L)
     return v;
 }
 
-// Sizes a lane's slot pool and staging array for `frames` frames of the pixels dealt to lane `lane` of `n_lanes`.
+// Sizes a lane's sample queues and staging array for `frames` frames of the pixels dealt to lane `lane` of `n_lanes`.
 static int wf_prepare(pt_ctx* c, pt_ctx::WfLane& L, int frames, int lane, int n_lanes, size_t pool_slots, int buf, WfParams* w)
 {
     size_t npix = (size_t)c->W * c->H;
