@@ -173,7 +173,7 @@ def main():
         P.isRendering = 1
         r = ptamd.Renderer(device)
         r.init(P)
-        soup_flavour = ptlib.PT_BVH_GPU_PLOC if args.tree == 'ploc' else ptlib.PT_BVH_GPU_LBVH
+        soup_flavour = ptlib.PT_BVH_GPU_PLOC if args.tree == 'ploc' else (ptlib.PT_BVH_REFERENCE if args.tree == 'host' else ptlib.PT_BVH_GPU_LBVH)
         r.upload_scene(tris, mats, None, None, flavour=soup_flavour)
         r.upload_envmap(env4, cdf, env_total, P)
         n_tris = len(tris)
