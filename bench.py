@@ -374,7 +374,8 @@ def main():
             bound = 'hbm'
             achieved, peak, unit, frac_of = traffic / (kms * 1e-3) / 1e9, HBM_PEAK_GBS, 'GB/s', 'PMC bytes that reached the memory side (FETCH_SIZE + WRITE_SIZE, profiles/pmc_traffic.json) / launch time / HBM peak'
         else:
-            bound = 'valu_issue'
+            # (neither resource near its ceiling: the waves wait on dependent memory reads; the larger share is reported)
+            bound = 'valu_issue' if valu >= 0.7 else 'latency (neither vector issue nor HBM bandwidth is saturated; achieved is vector issue, the larger share)'
             achieved, peak, unit = insts / (kms * 1e-3) / 1e9, VALU_PEAK_GINST, 'Ginst/s'
             frac_of = ('vector instructions of a launch (SQ_INSTS_VALU of the committed counter pass) / launch time measured here / (%d SIMDs x %.1f GHz / 4 cycles per wave64 instruction); '
                        'the same pass puts the vector ALUs at valu_busy of their cycles with valu_lanes_per_instruction of the lanes active' % (N_SIMDS, CLOCK_GHZ))
