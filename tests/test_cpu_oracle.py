@@ -492,6 +492,73 @@ def test_reflection_lobes_are_reciprocal(family):
         assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(np.abs(a), 1e-6)), (family, V, L, a, b)
 
 
+@pytest.mark.parametrize('family', ['rough_diffuse', 'all_reflection_lobes'])
+def test_direct_light_of_the_integrator_equals_the_quadrature_of_the_rendering_equation(family):
+    """A pin on the integrator's bookkeeping that does not share its reading: a convex floor under a smooth environment
+    has no interreflection, so with two path vertices allowed the estimator of pathtrace (pathtracer.cu:405-490: the
+    light sample weighted against the bsdf density, :298-339, plus the bsdf sample that leaves the scene weighted
+    against the light density, :409-425, roulette, the one-channel estimate times three, :527-540) must average to
+    the integral of bsdf x cosine x environment radiance over the hemisphere. That integral is taken here by
+    quadrature from DisneyEval_2 and evalEnvmap alone. A wrong weight, a density used on the wrong side, a throughput
+    updated in the wrong order or a lost factor moves the mean by tens of percent; the tolerance is 3 %."""
+    from ptamd.types import TRI_DTYPE
+    from ptamd import lib as ptlib
+    mats = _mat(roughness=1.0) if family == 'rough_diffuse' else _mat(**_FAMILIES[family])
+    mats['baseColor'] = [0.8, 0.6, 0.3]
+    ext = 4000.0
+    tris = np.zeros(2, dtype=TRI_DTYPE)
+    p = np.array([[-ext, 0, -ext], [ext, 0, -ext], [ext, 0, ext], [-ext, 0, ext]], np.float32)
+    tris['a'][0], tris['b'][0], tris['c'][0] = p[0], p[2], p[1]
+    tris['a'][1], tris['b'][1], tris['c'][1] = p[0], p[3], p[2]
+    for k in ('nA', 'nB', 'nC'):
+        tris[k] = [0.0, 1.0, 0.0]
+    # a smooth environment (no sun: light samples land on texel corners, envmap_cuda.cu:64-66, so the sampled
+    # estimator is a Riemann sum over the texels, exact only for radiance that varies slowly across one)
+    eh, ew = 128, 256
+    v, u = np.meshgrid((np.arange(eh) + 0.5) / eh, (np.arange(ew) + 0.5) / ew, indexing='ij')
+    env = np.zeros((eh, ew, 4), np.float32)
+    env[..., 0] = 1.0 + 0.6 * np.sin(2 * math.pi * u) * np.sin(math.pi * v)
+    env[..., 1] = 0.8 + 0.5 * np.cos(2 * math.pi * u + 1.0) * np.sin(math.pi * v) ** 2
+    env[..., 2] = 1.2 - 0.9 * v
+    b = util.Bundle(tris, mats, (), env)
+    W, H, frames = 64, 48, 1500
+    P = ptamd.default_params(W, H)
+    P.rayOrigin = ptamd.Float3(0.0, 100.0, 0.0)
+    P.cameraAngle = ptamd.Float3(0.3, -0.9, 0.0)       # looking down at the floor
+    P.isRendering = 1
+    S = b.oracle(P)
+    acc, st = orc.render(S, P, 0, frames, 2)
+    mean = acc.astype(np.float64) / frames
+    assert st['rays'] > 2 * W * H * frames * 0.9        # nearly every sample reached the floor and traced its light sample
+    # quadrature: bsdf x cosine (DisneyEval_2 returns the product) x radiance over the upper hemisphere (y up)
+    nt, nphi = 192, 384
+    ct = (np.arange(nt) + 0.5) / nt
+    ph = (np.arange(nphi) + 0.5) / nphi * 2 * math.pi
+    CT, PH = np.meshgrid(ct, ph, indexing='ij')
+    stheta = np.sqrt(1 - CT ** 2)
+    L = np.stack([stheta * np.cos(PH), CT, stheta * np.sin(PH)], -1).reshape(-1, 3).astype(np.float32)
+    dw = 2 * math.pi / (nt * nphi)
+    radiance = np.array([orc.env_eval(S, d)[:3] for d in L], np.float64)
+    ww, uu, vv = orc.camera_basis(P)
+    N = np.array([0, 1, 0], np.float32)
+    rng = np.random.default_rng(5)
+    total_mc = total_q = 0.0
+    for x, y in zip(rng.integers(4, W - 4, 12), rng.integers(4, H - 4, 12)):
+        # the ray through the middle of the pixel's jitter (pathtracer.cu:563-570 with both draws at 0.5)
+        cx = ((x + 0.0) / W - 0.5) * (W / H)
+        cy = (1.0 - (y + 0.0) / H) - 0.5
+        rd = uu * cx + vv * cy + ww * P.fov
+        rd = rd / np.linalg.norm(rd)
+        assert rd[1] < -0.2
+        f, _ = orc.bsdf_eval_batch(mats, 0, (-rd).astype(np.float32), N, L)
+        q = (f.astype(np.float64) * radiance).sum(0) * dw
+        # the footprint of a pixel is two pixels wide: its neighbours see nearly the same point
+        mc = mean[y - 1:y + 2, x - 1:x + 2].mean((0, 1))
+        assert np.all(np.abs(mc - q) <= 0.12 * q), (family, x, y, mc, q)
+        total_mc += mc.sum(); total_q += q.sum()
+    assert abs(total_mc / total_q - 1.0) <= 0.03, (family, total_mc, total_q)
+
+
 def test_sky_gradient_brightest_toward_the_sun():
     sun = np.array([1, 0.7, -1], np.float32); sun /= np.linalg.norm(sun)
     at_sun = orc.sky_gradient(sun, sun)
