@@ -492,15 +492,17 @@ def test_reflection_lobes_are_reciprocal(family):
         assert np.all(np.abs(a - b) <= 1e-5 * np.maximum(np.abs(a), 1e-6)), (family, V, L, a, b)
 
 
-@pytest.mark.parametrize('family', ['rough_diffuse', 'all_reflection_lobes'])
-def test_direct_light_of_the_integrator_equals_the_quadrature_of_the_rendering_equation(family):
+@pytest.mark.parametrize('family,sky', [('rough_diffuse', 0), ('all_reflection_lobes', 0), ('all_reflection_lobes', 1)])
+def test_direct_light_of_the_integrator_equals_the_quadrature_of_the_rendering_equation(family, sky):
     """A pin on the integrator's bookkeeping that does not share its reading: a convex floor under a smooth environment
     has no interreflection, so with two path vertices allowed the estimator of pathtrace (pathtracer.cu:405-490: the
     light sample weighted against the bsdf density, :298-339, plus the bsdf sample that leaves the scene weighted
     against the light density, :409-425, roulette, the one-channel estimate times three, :527-540) must average to
     the integral of bsdf x cosine x environment radiance over the hemisphere. That integral is taken here by
     quadrature from DisneyEval_2 and evalEnvmap alone. A wrong weight, a density used on the wrong side, a throughput
-    updated in the wrong order or a lost factor moves the mean by tens of percent; the tolerance is 3 %."""
+    updated in the wrong order or a lost factor moves the mean by tens of percent; the tolerance is 3 %.
+    sky = 1: the sun/sky mode (no light samples: the bsdf sample alone carries the sky's radiance, pathtracer.cu:340-363),
+    with the sun below the horizon, where the sky function is bounded."""
     from ptamd.types import TRI_DTYPE
     from ptamd import lib as ptlib
     mats = _mat(roughness=1.0) if family == 'rough_diffuse' else _mat(**_FAMILIES[family])
@@ -520,16 +522,20 @@ def test_direct_light_of_the_integrator_equals_the_quadrature_of_the_rendering_e
     env[..., 0] = 1.0 + 0.6 * np.sin(2 * math.pi * u) * np.sin(math.pi * v)
     env[..., 1] = 0.8 + 0.5 * np.cos(2 * math.pi * u + 1.0) * np.sin(math.pi * v) ** 2
     env[..., 2] = 1.2 - 0.9 * v
-    b = util.Bundle(tris, mats, (), env)
+    b = util.Bundle(tris, mats, (), env, sky_mode=sky)
     W, H, frames = 64, 48, 1500
     P = ptamd.default_params(W, H)
     P.rayOrigin = ptamd.Float3(0.0, 100.0, 0.0)
     P.cameraAngle = ptamd.Float3(0.3, -0.9, 0.0)       # looking down at the floor
     P.isRendering = 1
+    if sky:
+        sun = np.array([0.3, -0.5, 0.2]); sun /= np.linalg.norm(sun)
+        P.sunDirection = ptamd.Float3(*[float(v) for v in sun])
     S = b.oracle(P)
     acc, st = orc.render(S, P, 0, frames, 2)
     mean = acc.astype(np.float64) / frames
-    assert st['rays'] > 2 * W * H * frames * 0.9        # nearly every sample reached the floor and traced its light sample
+    # nearly every sample reached the floor and traced its light sample (sky mode: its bounce, when roulette let it live)
+    assert st['rays'] > (1.4 if sky else 1.8) * W * H * frames
     # quadrature: bsdf x cosine (DisneyEval_2 returns the product) x radiance over the upper hemisphere (y up)
     nt, nphi = 192, 384
     ct = (np.arange(nt) + 0.5) / nt
@@ -538,7 +544,10 @@ def test_direct_light_of_the_integrator_equals_the_quadrature_of_the_rendering_e
     stheta = np.sqrt(1 - CT ** 2)
     L = np.stack([stheta * np.cos(PH), CT, stheta * np.sin(PH)], -1).reshape(-1, 3).astype(np.float32)
     dw = 2 * math.pi / (nt * nphi)
-    radiance = np.array([orc.env_eval(S, d)[:3] for d in L], np.float64)
+    if sky:
+        radiance = np.array([orc.sky_gradient(d, S.sun) for d in L], np.float64)
+    else:
+        radiance = np.array([orc.env_eval(S, d)[:3] for d in L], np.float64)
     ww, uu, vv = orc.camera_basis(P)
     N = np.array([0, 1, 0], np.float32)
     rng = np.random.default_rng(5)
@@ -554,9 +563,9 @@ def test_direct_light_of_the_integrator_equals_the_quadrature_of_the_rendering_e
         q = (f.astype(np.float64) * radiance).sum(0) * dw
         # the footprint of a pixel is two pixels wide: its neighbours see nearly the same point
         mc = mean[y - 1:y + 2, x - 1:x + 2].mean((0, 1))
-        assert np.all(np.abs(mc - q) <= 0.12 * q), (family, x, y, mc, q)
+        assert np.all(np.abs(mc - q) <= 0.12 * q), (family, sky, x, y, mc, q)
         total_mc += mc.sum(); total_q += q.sum()
-    assert abs(total_mc / total_q - 1.0) <= 0.03, (family, total_mc, total_q)
+    assert abs(total_mc / total_q - 1.0) <= 0.03, (family, sky, total_mc, total_q)
 
 
 def test_sky_gradient_brightest_toward_the_sun():
