@@ -240,6 +240,32 @@ def test_sample_queues_shrink_when_the_device_is_short_of_memory():
     assert iters_short > iters_all                    # the samples went through in several turns
 
 
+def test_random_configurations_agree_between_the_kernel_organisations():
+    """Sixteen random combinations of image size (tiled and row-major sample order), frame range, samples in flight,
+    staging chunk, lanes, drain threshold, bounce cap, thin lens, sky mode and scene: the stage kernels over the striped
+    queues and the one-kernel-per-sample mode give the same accumulator bits (tools/fuzz_modes.py runs more)."""
+    rng = np.random.default_rng(11)
+    bundles = [(util.cornell('sky'), scenes.cornell_params), (util.atrium(detail=0.25), scenes.atrium_params),
+               (util.atrium(detail=0.25, glossy=0.3, glass=0.3, sky_mode=1), scenes.atrium_params)]
+    for case in range(16):
+        b, mkparams = bundles[int(rng.integers(len(bundles)))]
+        W, H = int(rng.integers(1, 160)), int(rng.integers(1, 100))
+        if rng.random() < 0.4:
+            W, H = W // 8 * 8 + 8, H // 8 * 8 + 8
+        f0, frames = int(rng.integers(0, 5)), int(rng.integers(1, 7))
+        pool, chunk = int(rng.choice([64, 256, 700, 4096, 65536, 1 << 27])), int(rng.choice([1, 2, 3, 64]))
+        lanes, drain, bounces = int(rng.integers(1, 3)), int(rng.choice([0, 64, 5000, 262144])), int(rng.choice([1, 2, 5, 12]))
+        P = mkparams(ptamd.default_params(W, H))
+        if rng.random() < 0.3:
+            P.DOF_strenght = 2.0
+        r = b.renderer(P, 0)
+        r.set_max_bounces(bounces); r.set_pool(pool, chunk); r.set_lanes(lanes); r.set_drain(drain)
+        r.set_mode(1); r.clear_accum(); r.render(P, f0, f0 + frames); want = r.read_accum()
+        r.set_mode(0); r.clear_accum(); r.render(P, f0, f0 + frames); got = r.read_accum()
+        r.close()
+        assert np.array_equal(bits(got), bits(want)), (case, W, H, f0, frames, pool, chunk, lanes, drain, bounces)
+
+
 def test_render_frame_matches_reference_frame_loop():
     """pt_render_frame == render(): 1 spp per call, frame 0 overwrites, RGBA8 of accum/(frame+1)."""
     b = util.cornell('sky')
