@@ -78,6 +78,7 @@ struct DScene {
     float q_origin[3], q_cell[3], q_inv_cell[3];
     const DTri* tris;             // leaf order
     const pt_triangle* tri_ref;   // original order, reference layout (shading attributes)
+    const uint8_t* tri_opaque;    // original order: DMat::opaque of the triangle's material (one dependent load instead of two for the visibility walk), or null
     const DMat* mats;
     const DTex* tex;
     const float* env_rgba;

@@ -997,8 +997,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
         const uint32_t stripe = blk & (uint32_t)(kStripes - 1);
         const uint32_t i = blk * kBlock + threadIdx.x;
         const bool in_block = threadIdx.x < block_fill(blk, counts);
-        float4 sd4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (in_block) sd4 = w.Sc.sd[i];
+        // (the hit and the state word are fetched with the segment, not after it: nearly every record of a launch that
+        // has any still waits for its hit, and the chain of dependent loads is one shorter)
+        float4 sd4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = sd4, c2_in = sd4;
+        if (in_block) { sd4 = w.Sc.sd[i]; h4 = w.hitS[i]; c2_in = w.Sc.c2[i]; }
         // a record without a pending ray was handed to the bsdf stage when it was written (see wf_vertex_kernel)
         const bool have = in_block && __float_as_int(sd4.w) != 0;
         Path P;
@@ -1009,8 +1011,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
         // left one earlier (sd.w == 2). For every other walk it is still the (1, 1, 1) its vertex wrote.
         bool light_loaded = false, light_changed = false;
         if (have) {
-            float4 h4 = w.hitS[i];
-            c2 = w.Sc.c2[i];
+            c2 = c2_in;
             unpack_flags(P, __float_as_uint(c2.y));
             if (P.sh_inside || __float_as_int(sd4.w) == 2) {
                 float4 l0 = w.Sc.d0[i];
@@ -1024,7 +1025,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
             // number and fails, the transmittance is zero (pathtracer.cu:279-295). Most hits are of this kind and
             // skip the texture coordinates, the material record, the texels and the random-number block.
             bool opaque = false;
-            if (!COUNT && h.tri != PT_NO_TRI) opaque = S.mats[S.tri_ref[h.tri].matIndex].opaque != 0;
+            if (!COUNT && h.tri != PT_NO_TRI) opaque = S.tri_opaque ? S.tri_opaque[h.tri] != 0 : S.mats[S.tri_ref[h.tri].matIndex].opaque != 0;
             if (opaque) {
                 P.rng.draws = __float_as_uint(c2.z) + 1u;
                 P.light = f3(0.f, 0.f, 0.f);
