@@ -90,7 +90,7 @@ struct pt_ctx {
     std::vector<int> tri_idx;
     // scene, device
     pt_triangle* d_tri_ref = nullptr;
-    uint8_t* d_tri_opaque = nullptr;        // per triangle: its material's opaque flag (rebuilt when triangles or materials change)
+    uint32_t* d_tri_info = nullptr;         // per triangle: material index and its material's opaque flag (rebuilt when triangles or materials change)
     std::vector<uint8_t> mat_opaque;
     bool tri_flags_stale = true;
     DTri* d_tris = nullptr;
@@ -280,7 +280,7 @@ void pt_destroy(pt_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     free_scene_geometry(c);
     if (c->d_tri_ref) (void)hipFree(c->d_tri_ref);
-    if (c->d_tri_opaque) (void)hipFree(c->d_tri_opaque);
+    if (c->d_tri_info) (void)hipFree(c->d_tri_info);
     if (c->d_mats) (void)hipFree(c->d_mats);
     if (c->d_tex) (void)hipFree(c->d_tex);
     for (void* p : c->tex_data) (void)hipFree(p);
@@ -366,7 +366,7 @@ int pt_upload_triangles(pt_ctx* c, const int* tri_idx, const pt_triangle* tris, 
     c->scene.tri_ref = c->d_tri_ref;
     c->scene.n_tris = n;
     c->have_tris = true;
-    c->tri_flags_stale = true; c->scene.tri_opaque = nullptr;
+    c->tri_flags_stale = true; c->scene.tri_info = nullptr;
     return PT_OK;
 }
 
@@ -411,7 +411,7 @@ int pt_upload_materials(pt_ctx* c, const pt_material* mats, int n)
     }
     c->mat_opaque.resize((size_t)n);
     for (int i = 0; i < n; i++) c->mat_opaque[(size_t)i] = (uint8_t)dm[(size_t)i].opaque;
-    c->tri_flags_stale = true; c->scene.tri_opaque = nullptr;
+    c->tri_flags_stale = true; c->scene.tri_info = nullptr;
     if (c->have_tris) {
         for (size_t i = 0; i < c->tris.size(); i++)
             if (c->tris[i].matIndex < 0 || c->tris[i].matIndex >= n) { set_error("triangle %zu uses material %d of %d", i, c->tris[i].matIndex, n); return PT_ERR_ARG; }
@@ -1050,18 +1050,18 @@ static int check_ready(pt_ctx* c, bool need_image)
         if (c->scene.sky_mode == PT_SKY_ENVMAP && !c->have_env) { set_error("scene not ready: upload an environment map or select the sun/sky model"); return PT_ERR_STATE; }
     }
     if (need_image && c->tri_flags_stale) {
-        // the opaque flag of every triangle's material, in triangle order: the visibility walk reads it with one
-        // load from a table that stays in the caches instead of triangle -> material index -> material
-        std::vector<uint8_t> flags(c->tris.size());
+        // material index and opaque flag of every triangle, in triangle order (DScene::tri_info)
+        std::vector<uint32_t> info(c->tris.size());
         for (size_t i = 0; i < c->tris.size(); i++) {
             const int m = c->tris[i].matIndex;
-            flags[i] = (m >= 0 && (size_t)m < c->mat_opaque.size()) ? c->mat_opaque[(size_t)m] : (uint8_t)0;
+            const bool known = m >= 0 && (size_t)m < c->mat_opaque.size();
+            info[i] = (uint32_t)(known ? m : 0) | ((known && c->mat_opaque[(size_t)m]) ? 0x80000000u : 0u);
         }
         HIP_TRY(hipSetDevice(c->device));
-        if (c->d_tri_opaque) { (void)hipFree(c->d_tri_opaque); c->d_tri_opaque = nullptr; }
-        HIP_TRY(hipMalloc((void**)&c->d_tri_opaque, flags.size()));
-        HIP_TRY(hipMemcpy(c->d_tri_opaque, flags.data(), flags.size(), hipMemcpyHostToDevice));
-        c->scene.tri_opaque = c->d_tri_opaque;
+        if (c->d_tri_info) { (void)hipFree(c->d_tri_info); c->d_tri_info = nullptr; }
+        HIP_TRY(hipMalloc((void**)&c->d_tri_info, info.size() * sizeof(uint32_t)));
+        HIP_TRY(hipMemcpy(c->d_tri_info, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->scene.tri_info = c->d_tri_info;
         c->tri_flags_stale = false;
     }
     return PT_OK;

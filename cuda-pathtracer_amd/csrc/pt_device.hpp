@@ -490,11 +490,13 @@ PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& 
     if (!s.hit) return;
     const pt_triangle* T = S.tri_ref + h.tri;
     const float4* tq = reinterpret_cast<const float4*>(T);      // 112 bytes = 7 x 16
+    uint32_t info = 0;
+    if (S.tri_info) info = S.tri_info[h.tri];       // (issued with the triangle's loads: the material does not wait for them)
     float4 t0 = tq[0], t1 = tq[1], t2 = tq[2], t3 = tq[3], t4 = tq[4], t5 = tq[5], t6 = tq[6];
     F3 a = f3(t0.x, t0.y, t0.z), b = f3(t0.w, t1.x, t1.y), c = f3(t1.z, t1.w, t2.x);
     F3 nA = f3(t3.x, t3.y, t3.z), nB = f3(t3.w, t4.x, t4.y), nC = f3(t4.z, t4.w, t5.x);
     F2 tA = {t5.y, t5.z}, tB = {t5.w, t6.x}, tC = {t6.y, t6.z};
-    int mi = __float_as_int(t6.w);
+    int mi = S.tri_info ? (int)(info & 0x7FFFFFFFu) : __float_as_int(t6.w);
     const DMat& M = S.mats[mi];
     const float4* mq = reinterpret_cast<const float4*>(&M);
     float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3], m4 = mq[4], m5 = mq[5], m6 = mq[6];

@@ -840,7 +840,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RESOL
             float4 d4 = w.Pc.c1[i];
             resolve_hit<COUNT>(S, h, f3(d4.x, d4.y, d4.z), info, tl.taps, tl.taps_r, false);
             info.m.rough = pt_fmaxf(info.m.rough, 0.0001f);         // pathtracer.cu:427
-            mat_index = S.tri_ref[h.tri].matIndex;
+            mat_index = S.tri_info ? (int)(S.tri_info[h.tri] & 0x7FFFFFFFu) : S.tri_ref[h.tri].matIndex;
         }
         Appends a;
         a.want[0] = hit; a.tail[0] = w.counters + WF_CTR_TAIL_S;
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
             // number and fails, the transmittance is zero (pathtracer.cu:279-295). Most hits are of this kind and
             // skip the texture coordinates, the material record, the texels and the random-number block.
             bool opaque = false;
-            if (!COUNT && h.tri != PT_NO_TRI) opaque = S.tri_opaque ? S.tri_opaque[h.tri] != 0 : S.mats[S.tri_ref[h.tri].matIndex].opaque != 0;
+            if (!COUNT && h.tri != PT_NO_TRI) opaque = S.tri_info ? (S.tri_info[h.tri] >> 31) != 0 : S.mats[S.tri_ref[h.tri].matIndex].opaque != 0;
             if (opaque) {
                 P.rng.draws = __float_as_uint(c2.z) + 1u;
                 P.light = f3(0.f, 0.f, 0.f);
