@@ -63,16 +63,16 @@ def requested_bytes(c, packed_textures):
     return {
         # both queues: origin + direction in (32), hit out (16); 64 per wide node visited, 48 per triangle tested
         'extend': 48 * c['rays'] + 64 * c['wide_nodes'] + 48 * c['wide_tris'],
-        # hit and direction in (32), shading triangle (112), material (128), texels; link + vertex arrays out (96); misses listed (4)
-        'resolve': 32 * c['path_rays'] + (112 + 128 + 96) * hits + tap4 * material_taps + tap1 * c['tex_taps_r'] * 0.5 + 4 * misses,
-        # link, vertex arrays and path record in (144); light sample: guide, column table, per-texel values (48); ray, path state, light out (112)
-        'vertex': (144 + 112) * hits + 48 * env,
+        # hit and direction in (32), shading triangle (112), material (128), texels; link + vertex arrays out (64); misses listed (4)
+        'resolve': 32 * c['path_rays'] + (112 + 128 + 64) * hits + tap4 * material_taps + tap1 * c['tex_taps_r'] * 0.5 + 4 * misses,
+        # link, vertex arrays and path record in (112), the material's constants (64, from the caches); light sample: guide, column table, per-texel values (48); ray, path state, light out (112)
+        'vertex': (112 + 64 + 112) * hits + 48 * env,
         # list entry and path record in (52), four environment texels (64), a new camera ray out (48)
         'miss': (52 + 64 + 48) * misses,
         # direction, hit and state in (48), uv words of the shading triangle (32), material (128), alpha/metallic texels; state out (16), list entry (4)
         'shadow': (48 + 32 + 128 + 20) * segments + tap1 * c['tex_taps_r'] * 0.5,
-        # list entry and whole record in (196), continuing path out (48)
-        'bsdf': (196 + 48) * hits,
+        # list entry and whole record in (164), the material's constants (64, from the caches), continuing path out (48)
+        'bsdf': (164 + 64 + 48) * hits,
     }
 
 

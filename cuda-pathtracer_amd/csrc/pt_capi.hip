@@ -123,8 +123,8 @@ struct pt_ctx {
     size_t n_nodes = 0, n_nodes4 = 0;
     // wavefront pool
     int mode = PT_MODE_WAVEFRONT;
-    // Samples in flight at most: 520 bytes of queue arrays each, allocated for what a render needs (never more than its
-    // samples). 2^27 holds a whole 64-spp 1080p chunk (70 GB of the 288): no sample waits for a slot, and the stage
+    // Samples in flight at most: 456 bytes of queue arrays each, allocated for what a render needs (never more than its
+    // samples). 2^27 holds a whole 64-spp 1080p chunk (61 GB of the 288): no sample waits for a slot, and the stage
     // loop takes 28 iterations instead of 38. Bench: 2^24 -6 %, 2^25 -4.4 %, 2^26 -2.6 %.
     int pool_slots = 1 << 27;
     int chunk_frames = 512;         // frames per staging chunk: every chunk pays one ramp-up and one run-down of the pool
@@ -1114,11 +1114,11 @@ static size_t queue_capacity(const pt_ctx* c, size_t slots)
     return per_stripe * kStripes * 256;
 }
 
-// Bytes of a lane's queues: 32 arrays of 16 bytes per entry (two buffers each of the path queue's 3 and the shadow
-// queue's 12, and the two hit arrays), the bsdf list, the miss list, and the workgroups' sample-id chunks.
+// Bytes of a lane's queues: 28 arrays of 16 bytes per entry (two buffers each of the path queue's 3 and the shadow
+// queue's 10, and the two hit arrays), the bsdf list, the miss list, and the workgroups' sample-id chunks.
 static size_t pool_bytes(size_t capacity, int stage_blocks)
 {
-    size_t b = capacity * (32 * sizeof(float4) + 2 * sizeof(uint32_t)) + (size_t)stage_blocks * 2 * sizeof(uint32_t);
+    size_t b = capacity * (28 * sizeof(float4) + 2 * sizeof(uint32_t)) + (size_t)stage_blocks * 2 * sizeof(uint32_t);
     return (b + 255) / 256 * 256;
 }
 
@@ -1132,7 +1132,7 @@ static void pool_layout(pt_ctx::WfLane& L, void* base_ptr, size_t capacity, int 
         P.c0 = take(); P.c1 = take(); P.c2 = take();
         WfShadowQueue& S = L.shadow_q[k];
         S.so = take(); S.sd = take(); S.c0 = take(); S.c1 = take(); S.c2 = take(); S.d0 = take(); S.d1 = take();
-        S.e0 = take(); S.e1 = take(); S.e2 = take(); S.e3 = take(); S.e4 = take();
+        S.e0 = take(); S.e1 = take(); S.e4 = take();
     }
     w->hitP = take(); w->hitS = take();
     w->bsdf_list = (uint32_t*)p;
@@ -1156,7 +1156,7 @@ static int lane_pool(pt_ctx* c, pt_ctx::WfLane& L, size_t slots, WfParams* w)
         if (e == hipSuccess) { L.block_bytes = need; break; }
         L.block = nullptr;
         (void)hipGetLastError();
-        // The device does not have that much memory free (the default asks for up to 70 GB): fewer samples in flight
+        // The device does not have that much memory free (the default asks for up to 61 GB): fewer samples in flight
         // change the number of stage iterations, never a result.
         if (e != hipErrorOutOfMemory || slots <= ((size_t)1 << 20)) { set_error("hipMalloc of %zu bytes for the sample queues: %s", need, hipGetErrorString(e)); return PT_ERR_HIP; }
         slots = (slots / 2 + 255) / 256 * 256;

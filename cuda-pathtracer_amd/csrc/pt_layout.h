@@ -127,7 +127,7 @@ struct DCounters {
 
 // ---------------------------------------------------------------- wavefront queues
 // A sample in flight is one record in one of two queues, by what it waits for: the closest hit of its path ray
-// (path queue, 48 bytes) or of a segment of the visibility walk of its light sample (shadow queue, 192 bytes: the
+// (path queue, 48 bytes) or of a segment of the visibility walk of its light sample (shadow queue, 160 bytes: the
 // path state, the light sample and the vertex the walk started from). Both are structures of 16-byte arrays indexed
 // by queue position, and both are dense: every stage reads the current queues front to back and appends what it
 // produces to the next ones (positions handed out by one atomic per workgroup and queue), so a wave's 64 records
@@ -137,7 +137,8 @@ struct WfShadowQueue {
     float4 *so, *sd;                // pending segment of the visibility walk; sd.w != 0 while the record waits for its hit
     float4 *c0, *c1, *c2;           // path state as in the path queue (o is the vertex position)
     float4 *d0, *d1;                // (transmittance so far, light pdf) (light radiance, 0)
-    float4 *e0, *e1, *e2, *e3, *e4; // vertex context: material values and shading normal
+    float4 *e0, *e1, *e4;           // vertex context: what differs from hit to hit: (base colour, roughness) (emission, metallic) (shading normal, alpha); the
+                                    // material's other parameters are read from its record (so.w holds its index once the vertex stage has run, so.y before)
 };
 
 // Striped queues. One 32-bit word takes about 90 returning atomic adds per microsecond from the whole chip

@@ -123,34 +123,28 @@ PT_DEV uint32_t load_path(const WfPathQueue& q, uint32_t i, const WfParams& w, P
     P.so = P.sd = P.light = P.env_color = f3(0.f, 0.f, 0.f); P.env_pdf = 0.f;
     return load_core(q.c0, q.c1, q.c2, i, w, P, id);
 }
-// a whole record of the shadow queue; the record waits for the hit of (so, sd) while state is ST_SHADOW
-PT_DEV void store_shadow(const WfShadowQueue& q, uint32_t i, const Path& P, uint32_t sample)
+// A whole record of the shadow queue. The record carries the values of the vertex that differ from hit to hit (what
+// the texture maps and the shading normal give: e0, e1, e4) and the index of its material (so.w); the material's other
+// parameters, which no map changes (resolve_hit), are read from its record, which stays in the caches.
+PT_DEV void material_constants(const DScene& S, int mat_index, Mat& m)
 {
-    const Mat& m = P.vm;
-    q.so[i] = make_float4(P.so.x, P.so.y, P.so.z, 0.f);
-    q.sd[i] = make_float4(P.sd.x, P.sd.y, P.sd.z, __int_as_float(P.state == ST_SHADOW ? 1 : 0));
-    store_core(q.c0, q.c1, q.c2, i, P, sample);
-    q.d0[i] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
-    q.d1[i] = make_float4(P.env_color.x, P.env_color.y, P.env_color.z, 0.f);
-    q.e0[i] = make_float4(m.base.x, m.base.y, m.base.z, m.rough);
-    q.e1[i] = make_float4(m.emis.x, m.emis.y, m.emis.z, m.aniso);
-    q.e2[i] = make_float4(m.metal, m.subsurf, m.sheen, m.coat);
-    q.e3[i] = make_float4(m.coat_rough, m.strans, m.ior, m.G);
-    q.e4[i] = make_float4(P.vn.x, P.vn.y, P.vn.z, m.alpha);
+    const float4* mq = reinterpret_cast<const float4*>(S.mats + mat_index);
+    const float4 m1 = mq[1], m2 = mq[2], m3 = mq[3], m4 = mq[4];
+    m.aniso = m1.w; m.subsurf = m2.y; m.sheen = m2.z; m.coat = m2.w;
+    m.coat_rough = m3.x; m.strans = m3.y; m.ior = m3.w; m.G = m4.x;
 }
-PT_DEV uint32_t load_shadow(const WfShadowQueue& q, uint32_t i, const WfParams& w, Path& P, SampleId& id)
+PT_DEV uint32_t load_shadow(const WfShadowQueue& q, uint32_t i, const WfParams& w, const DScene& S, Path& P, SampleId& id)
 {
     float4 so = q.so[i], sd = q.sd[i], l0 = q.d0[i], l1 = q.d1[i];
-    float4 a = q.e0[i], b = q.e1[i], c = q.e2[i], d = q.e3[i], e = q.e4[i];
+    float4 a = q.e0[i], b = q.e1[i], e = q.e4[i];
     uint32_t sample = load_core(q.c0, q.c1, q.c2, i, w, P, id);
     P.so = f3(so.x, so.y, so.z); P.sd = f3(sd.x, sd.y, sd.z);
     P.light = f3(l0.x, l0.y, l0.z); P.env_pdf = l0.w;
     P.env_color = f3(l1.x, l1.y, l1.z);
     Mat& m = P.vm;
     m.base = f3(a.x, a.y, a.z); m.rough = a.w;
-    m.emis = f3(b.x, b.y, b.z); m.aniso = b.w;
-    m.metal = c.x; m.subsurf = c.y; m.sheen = c.z; m.coat = c.w;
-    m.coat_rough = d.x; m.strans = d.y; m.ior = d.z; m.G = d.w;
+    m.emis = f3(b.x, b.y, b.z); m.metal = b.w;
+    material_constants(S, __float_as_int(so.w), m);
     P.vn = f3(e.x, e.y, e.z); m.alpha = e.w;
     m.sigA = f3(0.f, 0.f, 0.f); m.sigS = f3(0.f, 0.f, 0.f);     // not used after the vertex
     return sample;
@@ -852,9 +846,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RESOL
             // (hit distance, material, -, path record): what the vertex stage needs beside the vertex arrays
             w.Sn.so[j] = make_float4(h.t, __int_as_float(mat_index), 0.f, __uint_as_float(i));
             w.Sn.e0[j] = make_float4(m.base.x, m.base.y, m.base.z, m.rough);
-            w.Sn.e1[j] = make_float4(m.emis.x, m.emis.y, m.emis.z, m.aniso);
-            w.Sn.e2[j] = make_float4(m.metal, m.subsurf, m.sheen, m.coat);
-            w.Sn.e3[j] = make_float4(m.coat_rough, m.strans, m.ior, m.G);
+            w.Sn.e1[j] = make_float4(m.emis.x, m.emis.y, m.emis.z, m.metal);
             w.Sn.e4[j] = make_float4(info.n.x, info.n.y, info.n.z, m.alpha);
         }
         if (a.want[1]) w.miss_list[a.pos[1]] = i;
@@ -890,17 +882,18 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTE
         uint32_t sample = kNone;
         P.state = ST_DONE;
         bool finished = false;
+        float mat_bits = 0.f;
         if (have) {
             const float4 link = w.Sn.so[j];
-            const float4 a = w.Sn.e0[j], b = w.Sn.e1[j], c = w.Sn.e2[j], d = w.Sn.e3[j], e = w.Sn.e4[j];
+            mat_bits = link.y;
+            const float4 a = w.Sn.e0[j], b = w.Sn.e1[j], e = w.Sn.e4[j];
             sample = load_path(w.Pc, __float_as_uint(link.w), w, P, id);
             Surf info;
             info.t = link.x; info.hit = true; info.inside = false;
             Mat& m = info.m;
             m.base = f3(a.x, a.y, a.z); m.rough = a.w;
-            m.emis = f3(b.x, b.y, b.z); m.aniso = b.w;
-            m.metal = c.x; m.subsurf = c.y; m.sheen = c.z; m.coat = c.w;
-            m.coat_rough = d.x; m.strans = d.y; m.ior = d.z; m.G = d.w;
+            m.emis = f3(b.x, b.y, b.z); m.metal = b.w;
+            material_constants(S, __float_as_int(link.y), m);
             info.n = f3(e.x, e.y, e.z); m.alpha = e.w;
             m.sigA = f3(0.f, 0.f, 0.f); m.sigS = f3(0.f, 0.f, 0.f);
             if (P.inside) {         // the medium this path travels in is described by the surface it meets (pathtracer.cu:432-433)
@@ -923,7 +916,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTE
         reserve<2>(ap, stripe);
         if (ap.want[0]) store_path(w.Pn, ap.pos[0], P, sample);
         if (stays) {
-            w.Sn.so[j] = make_float4(P.so.x, P.so.y, P.so.z, 0.f);
+            w.Sn.so[j] = make_float4(P.so.x, P.so.y, P.so.z, mat_bits);       // (the material index rides with the walk's origin)
             w.Sn.sd[j] = make_float4(P.sd.x, P.sd.y, P.sd.z, __int_as_float(P.state == ST_SHADOW ? 1 : 0));
             store_core(w.Sn.c0, w.Sn.c1, w.Sn.c2, j, P, sample);
             w.Sn.d0[j] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
@@ -1096,13 +1089,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
             // (P.so holds the step along the ray from the record's origin, see above)
             const float4 so4 = w.Sc.so[i];
             const F3 o = f3(so4.x, so4.y, so4.z) + P.so;
-            w.Sn.so[j] = make_float4(o.x, o.y, o.z, 0.f);
+            w.Sn.so[j] = make_float4(o.x, o.y, o.z, so4.w);
             w.Sn.sd[j] = make_float4(sd4.x, sd4.y, sd4.z, __int_as_float(light_loaded ? 2 : 1));
             w.Sn.c0[j] = w.Sc.c0[i]; w.Sn.c1[j] = w.Sc.c1[i];
             w.Sn.c2[j] = make_float4(c2.x, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), c2.w);
             w.Sn.d0[j] = light_loaded ? make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf) : w.Sc.d0[i];
             w.Sn.d1[j] = w.Sc.d1[i];
-            w.Sn.e0[j] = w.Sc.e0[i]; w.Sn.e1[j] = w.Sc.e1[i]; w.Sn.e2[j] = w.Sc.e2[i]; w.Sn.e3[j] = w.Sc.e3[i]; w.Sn.e4[j] = w.Sc.e4[i];
+            w.Sn.e0[j] = w.Sc.e0[i]; w.Sn.e1[j] = w.Sc.e1[i]; w.Sn.e4[j] = w.Sc.e4[i];
         }
     }
     flush_tally<COUNT>(ctr, tl, 0);
@@ -1134,8 +1127,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_BSDF_
         bool finished = false;
         if (have) {
             const uint32_t e = w.bsdf_list[k];
-            if (e >> 31) sample = load_shadow(w.Sn, e & 0x7FFFFFFFu, w, P, id);
-            else sample = load_shadow(w.Sc, e, w, P, id);
+            if (e >> 31) sample = load_shadow(w.Sn, e & 0x7FFFFFFFu, w, S, P, id);
+            else sample = load_shadow(w.Sc, e, w, S, P, id);
             after_light<COUNT>(S, cam, P, tl);
             finished = P.state == ST_DONE;
         }
@@ -1203,9 +1196,10 @@ __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, 
     if (have) {
         if (!from_shadow) load_path(w.Pc, q, w, P, id);
         else {
-            load_shadow(w.Sc, q, w, P, id);
-            // a record without a pending ray already went through the bsdf stage: its sample lives on elsewhere
+            // a record without a pending ray already went through the bsdf stage (its sample lives on elsewhere) or was
+            // left dead by the vertex stage, whose so.w is then not a material index: it is not loaded
             if (__float_as_int(w.Sc.sd[q].w) == 0) have = false;
+            else load_shadow(w.Sc, q, w, S, P, id);
         }
     }
     if (have) {

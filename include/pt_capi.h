@@ -181,7 +181,7 @@ int pt_set_env_guides(pt_ctx* ctx, int on, int* verified_out);           /* on (
 
 /* ---- headless rendering (replaces the window loop, main.cpp:247-296) ---- */
 int pt_set_mode(pt_ctx* ctx, int mode);                                 /* PT_MODE_*; both modes give identical accumulators */
-int pt_set_pool(pt_ctx* ctx, int slots, int chunk_frames);              /* samples in flight at most (default 134217728 = 2^27: 520 bytes of queue arrays each, allocated for what a render needs and never for more than its samples; a 64-spp 1080p render holds 70 GB) and frames per staging chunk (default 512; one float per pixel and frame of a chunk is held, and each chunk pays one ramp-up and run-down of the queues) */
+int pt_set_pool(pt_ctx* ctx, int slots, int chunk_frames);              /* samples in flight at most (default 134217728 = 2^27: 456 bytes of queue arrays each, allocated for what a render needs and never for more than its samples; a 64-spp 1080p render holds 61 GB) and frames per staging chunk (default 512; one float per pixel and frame of a chunk is held, and each chunk pays one ramp-up and run-down of the queues) */
 int pt_set_drain(pt_ctx* ctx, int max_rays);                            /* wavefront mode: once every sample is started and at most max_rays paths remain, finish them in one kernel (0 = never) */
 int pt_wavefront_stats(pt_ctx* ctx, uint64_t* iterations_out, uint64_t* drains_out); /* wavefront mode: stage-kernel iterations issued and drain kernels run since the context was created (either pointer may be null) */
 int pt_set_lanes(pt_ctx* ctx, int lanes);                                /* wavefront mode: number of concurrent lanes (streams), each with a share of the samples in flight and of the pixels: 1 (default) or 2; same accumulator bits */
