@@ -36,9 +36,18 @@ import numpy as np  # noqa: E402
 N_SIMDS, CLOCK_GHZ = 1024, 2.4      # 256 CUs x 4 SIMDs; one wave64 vector instruction per SIMD every 4 cycles
 VALU_PEAK_GINST = N_SIMDS * CLOCK_GHZ / 4
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E datasheet peak
-STAGES = ('extend', 'resolve', 'vertex', 'miss', 'shadow', 'bsdf')
+STAGES = ('extend', 'resolve', 'vertex', 'miss', 'shadow', 'bsdf')      # the slots of pt_stage_times
 KERNEL_NAMES = {'extend': 'wf_extend_kernel', 'resolve': 'wf_resolve_kernel', 'vertex': 'wf_vertex_kernel', 'miss': 'wf_miss_kernel',
-                'shadow': 'wf_shadow_kernel', 'bsdf': 'wf_bsdf_kernel'}
+                'shadow': 'wf_shadow_kernel', 'bsdf': 'wf_bsdf_kernel', 'path_hit': 'wf_pathhit_kernel'}
+
+
+def stage_kernels(sunsky):
+    """(name, slot of pt_stage_times) of the stage kernels an iteration launches. Scenes that draw light samples run both
+    halves of a path vertex in one kernel, timed in the resolve slot; sun/sky mode runs resolve and vertex (with the
+    bsdf stage inside) and has no shadow or bsdf launches that do work."""
+    if sunsky:
+        return [(n, n) for n in STAGES]
+    return [('extend', 'extend'), ('path_hit', 'resolve'), ('miss', 'miss'), ('shadow', 'shadow'), ('bsdf', 'bsdf')]
 
 
 def algorithmic_bytes(c):
@@ -63,7 +72,10 @@ def requested_bytes(c, packed_textures):
     return {
         # both queues: origin + direction in (32), hit out (16); 64 per wide node visited, 48 per triangle tested
         'extend': 48 * c['rays'] + 64 * c['wide_nodes'] + 48 * c['wide_tris'],
-        # hit and direction in (32), shading triangle (112), material (128), texels; link + vertex arrays out (64); misses listed (4)
+        # hit and path record in (64), shading triangle (112), material (128), texels; light sample: guide, column table, per-texel values (48);
+        # out: a whole shadow record for a vertex with a light sample (160), a path record for a ray that passed through (48); misses listed (4)
+        'path_hit': 64 * c['path_rays'] + (112 + 128) * hits + tap4 * material_taps + tap1 * c['tex_taps_r'] * 0.5 + (48 + 160) * env + 48 * max(hits - env, 0.0) + 4 * misses,
+        # the two-kernel form (sun/sky mode). resolve: hit and direction in (32), shading triangle (112), material (128), texels; link + vertex arrays out (64); misses listed (4)
         'resolve': 32 * c['path_rays'] + (112 + 128 + 64) * hits + tap4 * material_taps + tap1 * c['tex_taps_r'] * 0.5 + 4 * misses,
         # link, vertex arrays and path record in (112), the material's constants (64, from the caches); light sample: guide, column table, per-texel values (48); ray, path state, light out (112)
         'vertex': (112 + 64 + 112) * hits + 48 * env,
@@ -334,13 +346,13 @@ def main():
             # the layout-independent accounting on the reference's binary walk
             ref_per_launch = (40 * loc['rays'] + 32 * loc['box_tests'] + 48 * loc['tri_tests']) / args.steps / launches
             alg_per_launch = own_per_launch if loc['wide_nodes'] > 0 else ref_per_launch
-            for name in STAGES:
+            for name, slot in stage_kernels(args.workload == 'sunsky'):
                 e = pmk.get(KERNEL_NAMES[name], {})
-                k_ms = ms_one[name] / launches_one
+                k_ms = ms_one[slot] / launches_one
                 req_launch = req[name] / args.steps / launches_one
                 kernels.append({
                     'kernel': KERNEL_NAMES[name],
-                    'ms_per_step': round(ms_one[name], 3), 'ms_per_step_timed_config': round(ms_timed[name], 3),
+                    'ms_per_step': round(ms_one[slot], 3), 'ms_per_step_timed_config': round(ms_timed[slot], 3),
                     'launches_per_step': int(launches_one), 'ms_per_launch': round(k_ms, 4),
                     'requested_bytes_per_launch': int(req_launch),
                     'requested_GBs': round(req_launch / (k_ms * 1e-3) / 1e9, 1) if k_ms > 0 else None,

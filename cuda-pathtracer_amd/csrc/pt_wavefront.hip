@@ -104,9 +104,8 @@ PT_DEV void store_core(float4* c0, float4* c1, float4* c2, uint32_t i, const Pat
     c1[i] = make_float4(P.d.x, P.d.y, P.d.z, P.pdf);
     c2[i] = make_float4(P.result, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), __uint_as_float(sample));
 }
-PT_DEV uint32_t load_core(const float4* c0, const float4* c1, const float4* c2, uint32_t i, const WfParams& w, Path& P, SampleId& id)
+PT_DEV uint32_t unpack_core(const float4& a, const float4& b, const float4& c, const WfParams& w, Path& P, SampleId& id)
 {
-    float4 a = c0[i], b = c1[i], c = c2[i];
     P.o = f3(a.x, a.y, a.z); P.thr = a.w;
     P.d = f3(b.x, b.y, b.z); P.pdf = b.w;
     P.result = c.x;
@@ -115,6 +114,11 @@ PT_DEV uint32_t load_core(const float4* c0, const float4* c1, const float4* c2, 
     id = decode_sample(w, sample);
     rng_seed(P.rng, id.pixel, (uint32_t)id.frame, __float_as_uint(c.z));
     return sample;
+}
+PT_DEV uint32_t load_core(const float4* c0, const float4* c1, const float4* c2, uint32_t i, const WfParams& w, Path& P, SampleId& id)
+{
+    float4 a = c0[i], b = c1[i], c = c2[i];
+    return unpack_core(a, b, c, w, P, id);
 }
 PT_DEV void store_path(const WfPathQueue& q, uint32_t i, const Path& P, uint32_t sample) { store_core(q.c0, q.c1, q.c2, i, P, sample); }
 // a record of the path queue; the fields only a light sample sets start out cleared
@@ -810,6 +814,8 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
 // so it runs as a kernel of its own with few registers and many waves per SIMD to hide the chain. Every hit gets
 // its position in the next shadow queue here, and the resolved surface is written straight into that record's
 // vertex arrays; the vertex stage fills in the rest. Rays that left the scene are listed for the miss stage.
+// (Launched in sun/sky mode, whose vertex kernel carries the bsdf stage; scenes with light samples run both halves in
+// wf_pathhit_kernel.)
 #ifndef PT_RESOLVE_WAVES
 #define PT_RESOLVE_WAVES 5      // (4: -1.7 % on the bench; 6 spills)
 #endif
@@ -925,6 +931,77 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTE
             w.Sn.sd[j] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));       // a dead record: no ray, no sample
         }
         if (ap.want[1]) w.bsdf_list[ap.pos[1]] = j | 0x80000000u;
+    }
+    flush_tally<COUNT>(ctr, tl, nsamples);
+}
+
+// ---------------------------------------------------------------- path hit (resolve and vertex in one kernel)
+// Both halves of a path vertex on the state in registers, for scenes that draw light samples: the resolved surface
+// never travels through the record (64 bytes written and read back per hit in the two-kernel form), a record of the
+// next shadow queue is taken only by a vertex that drew a light sample, and the path record is fetched with the hit,
+// not after it. Four waves per SIMD (128 registers): +2.1 % on the bench against the two kernels; at three the same as
+// the two kernels, at five 112 spilled registers. -DPT_FUSED_PATH_STAGE=0 selects the two kernels for comparison; the
+// sun/sky mode always uses them (its vertex kernel carries the bsdf stage, which does not fit beside the resolve half).
+#ifndef PT_FUSED_PATH_STAGE
+#define PT_FUSED_PATH_STAGE 1
+#endif
+#ifndef PT_PATHHIT_WAVES
+#define PT_PATHHIT_WAVES 4
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_PATHHIT_WAVES))) void wf_pathhit_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+{
+    __shared__ uint32_t counts[kStripes];
+    BlockCursor bc = first_block(w.counters + WF_CTR_SEG_PATH, w.counters + WF_CTR_N_P, 1, counts);
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t nsamples = 0;
+    for (;;) {
+        const uint32_t blk = next_block(w.counters + WF_CTR_SEG_PATH, counts, bc);
+        if (blk == kNone) break;                    // uniform over the workgroup
+        const uint32_t stripe = blk & (uint32_t)(kStripes - 1);
+        const uint32_t i = blk * kBlock + threadIdx.x;
+        const bool have = threadIdx.x < block_fill(blk, counts);
+        Hit h; h.t = 0.f; h.tri = PT_NO_TRI; h.u = 0.f; h.v = 0.f;
+        if (have) { float4 h4 = w.hitP[i]; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w; }
+        const bool hit = have && h.tri != PT_NO_TRI;
+        Path P;
+        SampleId id = {0, 0, 0, 0u, 0u};
+        uint32_t sample = kNone;
+        P.state = ST_DONE;
+        bool finished = false;
+        float mat_bits = 0.f;
+        float4 pc0, pc1, pc2;           // (fetched beside the hit: one dependent load less; the one ray in six that misses pays 48 bytes for nothing)
+        if (have) { pc0 = w.Pc.c0[i]; pc1 = w.Pc.c1[i]; pc2 = w.Pc.c2[i]; }
+        if (hit) {
+            P.so = P.sd = P.light = P.env_color = f3(0.f, 0.f, 0.f); P.env_pdf = 0.f;
+            sample = unpack_core(pc0, pc1, pc2, w, P, id);
+            Surf info;
+            resolve_hit<COUNT>(S, h, P.d, info, tl.taps, tl.taps_r, false);
+            mat_bits = __int_as_float(S.tri_info ? (int)(S.tri_info[h.tri] & 0x7FFFFFFFu) : S.tri_ref[h.tri].matIndex);
+            on_path_vertex<COUNT>(S, cam, P, info, tl);
+            finished = P.state == ST_DONE;
+        }
+        finish_and_regenerate<COUNT>(w, cam, P, sample, id, finished, nsamples);
+        const bool alive = hit && P.state != ST_DONE;
+        Appends a;
+        a.want[0] = alive && P.state == ST_PATH; a.tail[0] = w.counters + WF_CTR_TAIL_P;
+        a.want[1] = alive && P.state == ST_SHADOW; a.tail[1] = w.counters + WF_CTR_TAIL_S;
+        a.want[2] = have && !hit; a.tail[2] = w.counters + WF_CTR_TAIL_M;
+        reserve<3>(a, stripe);
+        if (a.want[0]) store_path(w.Pn, a.pos[0], P, sample);
+        if (a.want[1]) {
+            const uint32_t j = a.pos[1];
+            const Mat& m = P.vm;
+            w.Sn.so[j] = make_float4(P.so.x, P.so.y, P.so.z, mat_bits);
+            w.Sn.sd[j] = make_float4(P.sd.x, P.sd.y, P.sd.z, __int_as_float(1));
+            store_core(w.Sn.c0, w.Sn.c1, w.Sn.c2, j, P, sample);
+            w.Sn.d0[j] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
+            w.Sn.d1[j] = make_float4(P.env_color.x, P.env_color.y, P.env_color.z, 0.f);
+            w.Sn.e0[j] = make_float4(m.base.x, m.base.y, m.base.z, m.rough);
+            w.Sn.e1[j] = make_float4(m.emis.x, m.emis.y, m.emis.z, m.metal);
+            w.Sn.e4[j] = make_float4(P.vn.x, P.vn.y, P.vn.z, m.alpha);
+        }
+        if (a.want[2]) w.miss_list[a.pos[2]] = i;
     }
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
@@ -1370,11 +1447,15 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
 #define PT_STAGE(kernel, k, ...) do { \
         if (ctr) hipLaunchKernelGGL(kernel<true>, stage, block, 0, s, __VA_ARGS__); else hipLaunchKernelGGL(kernel<false>, stage, block, 0, s, __VA_ARGS__); \
         if (ev) (void)hipEventRecord(ev[k], s); } while (0)
-    PT_STAGE(wf_resolve_kernel, 2, w, S, ctr);
+    // path hits: one kernel for scenes that draw light samples (its time is reported in the resolve stage's place and the
+    // vertex stage's stays zero), resolve then vertex (with the bsdf stage inside) in sun/sky mode
+    const bool fused = PT_FUSED_PATH_STAGE && S.sky_mode != PT_SKY_SUNSKY;
+    if (fused) PT_STAGE(wf_pathhit_kernel, 2, w, S, cam, ctr);
+    else PT_STAGE(wf_resolve_kernel, 2, w, S, ctr);
     // (before anything else appends to the next shadow queue)
     if (S.sky_mode == PT_SKY_SUNSKY) {
         if (ctr) hipLaunchKernelGGL((wf_vertex_kernel<true, true>), stage, block, 0, s, w, S, cam, ctr); else hipLaunchKernelGGL((wf_vertex_kernel<false, true>), stage, block, 0, s, w, S, cam, ctr);
-    } else {
+    } else if (!fused) {
         if (ctr) hipLaunchKernelGGL((wf_vertex_kernel<true, false>), stage, block, 0, s, w, S, cam, ctr); else hipLaunchKernelGGL((wf_vertex_kernel<false, false>), stage, block, 0, s, w, S, cam, ctr);
     }
     if (ev) (void)hipEventRecord(ev[3], s);

@@ -12,7 +12,7 @@ import re
 import sys
 
 HBM_PEAK = 8.0e12
-KERNELS = ['wf_extend_kernel', 'wf_resolve_kernel', 'wf_vertex_kernel', 'wf_miss_kernel', 'wf_shadow_kernel', 'wf_bsdf_kernel']
+KERNELS = ['wf_extend_kernel', 'wf_pathhit_kernel', 'wf_resolve_kernel', 'wf_vertex_kernel', 'wf_miss_kernel', 'wf_shadow_kernel', 'wf_bsdf_kernel']
 
 
 def timed_variant(line, kernel):

@@ -942,7 +942,7 @@ def test_bench_two_ranks_on_one_gpu_match_one_rank():
     assert p.returncode == 0, p.stderr[-2000:]
     weak = json.loads([l for l in p.stdout.splitlines() if l.startswith('{')][-1])
     assert weak['scaling'] == 'weak' and weak['n_gpus'] == 2 and weak['image_mean'] > 0
-    assert [k['kernel'] for k in weak['roofline']['kernels']] == ['wf_extend_kernel', 'wf_resolve_kernel', 'wf_vertex_kernel', 'wf_miss_kernel', 'wf_shadow_kernel', 'wf_bsdf_kernel']
+    assert [k['kernel'] for k in weak['roofline']['kernels']] == ['wf_extend_kernel', 'wf_pathhit_kernel', 'wf_miss_kernel', 'wf_shadow_kernel', 'wf_bsdf_kernel']
     assert all(k['ms_per_step'] > 0 and k['requested_bytes_per_launch'] > 0 for k in weak['roofline']['kernels'])
     # weak mode: 3 spp per rank = frames [0, 6) in all, the same image again
     assert abs(weak['image_mean'] - one['image_mean']) <= 1e-4 * one['image_mean']
