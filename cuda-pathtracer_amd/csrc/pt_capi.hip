@@ -426,6 +426,7 @@ int pt_upload_materials(pt_ctx* c, const pt_material* mats, int n)
     }
     c->scene.mats = c->d_mats;
     c->scene.tex = c->d_tex;
+    c->scene.n_mats = n; c->scene.n_tex = (int)c->tex_table.size();
     c->have_mats = true;
     return PT_OK;
 }

@@ -151,15 +151,19 @@ PT_DEV float tex_mix(const Taps& t, float c00, float c10, float c01, float c11)
 {
     return (c00 * t.bx + c10 * t.ax) * t.by + (c01 * t.bx + c11 * t.ax) * t.ay;
 }
-PT_DEV float4 tex4(const float* texels, int w, int h, float u, float v)
+// (texel pointers come out of a descriptor in memory, so the compiler cannot know their address space: said here, the loads
+// are global loads instead of flat ones)
+#define PT_GLOBAL __attribute__((address_space(1)))
+PT_DEV float4 tex4(const PT_GLOBAL float* texels, int w, int h, float u, float v)
 {
     Taps t = tex_taps(w, h, u, v);
-    const float4* p = reinterpret_cast<const float4*>(texels);
-    float4 a = p[t.i00], b = p[t.i10], c = p[t.i01], d = p[t.i11];
+    typedef float __attribute__((ext_vector_type(4))) vec4;        // (the float4 class has no constructor from another address space)
+    const PT_GLOBAL vec4* p = (const PT_GLOBAL vec4*)texels;
+    const vec4 a = p[t.i00], b = p[t.i10], c = p[t.i01], d = p[t.i11];
     return make_float4(tex_mix(t, a.x, b.x, c.x, d.x), tex_mix(t, a.y, b.y, c.y, d.y),
                        tex_mix(t, a.z, b.z, c.z, d.z), tex_mix(t, a.w, b.w, c.w, d.w));
 }
-PT_DEV float tex1(const float* texels, int w, int h, float u, float v)
+PT_DEV float tex1(const PT_GLOBAL float* texels, int w, int h, float u, float v)
 {
     Taps t = tex_taps(w, h, u, v);
     return tex_mix(t, texels[t.i00], texels[t.i10], texels[t.i01], texels[t.i11]);
@@ -174,7 +178,7 @@ PT_DEV float unorm8(uint32_t k)
     float e = __builtin_fmaf(-q, 255.0f, kf);
     return __builtin_fmaf(e, r, q);
 }
-PT_DEV float4 tex4_u8(const uint32_t* texels, int w, int h, float u, float v)
+PT_DEV float4 tex4_u8(const PT_GLOBAL uint32_t* texels, int w, int h, float u, float v)
 {
     Taps t = tex_taps(w, h, u, v);
     uint32_t a = texels[t.i00], b = texels[t.i10], c = texels[t.i01], d = texels[t.i11];
@@ -183,18 +187,18 @@ PT_DEV float4 tex4_u8(const uint32_t* texels, int w, int h, float u, float v)
                        tex_mix(t, unorm8((a >> 16) & 255u), unorm8((b >> 16) & 255u), unorm8((c >> 16) & 255u), unorm8((d >> 16) & 255u)),
                        tex_mix(t, unorm8(a >> 24), unorm8(b >> 24), unorm8(c >> 24), unorm8(d >> 24)));
 }
-PT_DEV float tex1_u8(const uint8_t* texels, int w, int h, float u, float v)
+PT_DEV float tex1_u8(const PT_GLOBAL uint8_t* texels, int w, int h, float u, float v)
 {
     Taps t = tex_taps(w, h, u, v);
     return tex_mix(t, unorm8(texels[t.i00]), unorm8(texels[t.i10]), unorm8(texels[t.i01]), unorm8(texels[t.i11]));
 }
 PT_DEV float4 tex4_any(const DTex& tx, float u, float v)
 {
-    return tx.format ? tex4_u8(reinterpret_cast<const uint32_t*>(tx.texels), tx.w, tx.h, u, v) : tex4(reinterpret_cast<const float*>(tx.texels), tx.w, tx.h, u, v);
+    return tx.format ? tex4_u8((const PT_GLOBAL uint32_t*)tx.texels, tx.w, tx.h, u, v) : tex4((const PT_GLOBAL float*)tx.texels, tx.w, tx.h, u, v);
 }
 PT_DEV float tex1_any(const DTex& tx, float u, float v)
 {
-    return tx.format ? tex1_u8(reinterpret_cast<const uint8_t*>(tx.texels), tx.w, tx.h, u, v) : tex1(reinterpret_cast<const float*>(tx.texels), tx.w, tx.h, u, v);
+    return tx.format ? tex1_u8((const PT_GLOBAL uint8_t*)tx.texels, tx.w, tx.h, u, v) : tex1((const PT_GLOBAL float*)tx.texels, tx.w, tx.h, u, v);
 }
 
 // ---------------------------------------------------------------- intersection
@@ -478,8 +482,11 @@ PT_DEV void default_mat(Mat& m)          // structs.cuh:75-94
 #define PT_MARK(st, k) do { } while (0)
 #endif
 
-template <bool COUNT>
-PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& taps, uint32_t& taps_r, bool visibility_only = false, unsigned long long* marks = nullptr)
+// LOCAL: the material and texture-descriptor tables are read from the caller's copies (a kernel's LDS) instead of S.mats
+// and S.tex.
+template <bool COUNT, bool LOCAL = false>
+PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& taps, uint32_t& taps_r, bool visibility_only = false, unsigned long long* marks = nullptr,
+                        const float4* local_mats = nullptr, const DTex* local_tex = nullptr)
 {
     // visibility_only: the caller is a segment of the visibility walk, which looks at alpha, metallic, specTrans, ior and
     // the medium only (pathtracer.cu:279-295): the roughness, emission and normal maps are not fetched (the counting
@@ -497,8 +504,8 @@ PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& 
     F3 nA = f3(t3.x, t3.y, t3.z), nB = f3(t3.w, t4.x, t4.y), nC = f3(t4.z, t4.w, t5.x);
     F2 tA = {t5.y, t5.z}, tB = {t5.w, t6.x}, tC = {t6.y, t6.z};
     int mi = S.tri_info ? (int)(info & 0x7FFFFFFFu) : __float_as_int(t6.w);
-    const DMat& M = S.mats[mi];
-    const float4* mq = reinterpret_cast<const float4*>(&M);
+    const float4* mq = LOCAL ? local_mats + 8 * mi : reinterpret_cast<const float4*>(S.mats + mi);
+    const DTex* texs = LOCAL ? local_tex : S.tex;
     float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3], m4 = mq[4], m5 = mq[5], m6 = mq[6];
     s.m.base = f3(m0.x, m0.y, m0.z); s.m.emis = f3(m0.w, m1.x, m1.y);
     s.m.rough = m1.z; s.m.aniso = m1.w; s.m.metal = m2.x; s.m.subsurf = m2.y; s.m.sheen = m2.z; s.m.coat = m2.w;
@@ -517,20 +524,20 @@ PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& 
     float px = tA.x * w + tB.x * u + tC.x * v;
     float py = tA.y * w + tB.y * u + tC.y * v;
     if (tx_d) {
-        const DTex tx = S.tex[tx_d - 1];
+        const DTex tx = texs[tx_d - 1];
         float4 r = tex4_any(tx, px, py);
         s.m.base = f3(r.x, r.y, r.z) * r.w;
         s.m.alpha = r.w;
         if (COUNT) taps++;
     }
     PT_MARK(marks, 3);
-    if (tx_r && all) { const DTex tx = S.tex[tx_r - 1]; s.m.rough = tex1_any(tx, px, py); if (COUNT) taps_r++; }
-    if (tx_m) { const DTex tx = S.tex[tx_m - 1]; s.m.metal = tex1_any(tx, px, py); if (COUNT) taps_r++; }
-    if (tx_e && all) { const DTex tx = S.tex[tx_e - 1]; float r = tex1_any(tx, px, py); s.m.emis = f3(r, r, r); if (COUNT) taps_r++; }
+    if (tx_r && all) { const DTex tx = texs[tx_r - 1]; s.m.rough = tex1_any(tx, px, py); if (COUNT) taps_r++; }
+    if (tx_m) { const DTex tx = texs[tx_m - 1]; s.m.metal = tex1_any(tx, px, py); if (COUNT) taps_r++; }
+    if (tx_e && all) { const DTex tx = texs[tx_e - 1]; float r = tex1_any(tx, px, py); s.m.emis = f3(r, r, r); if (COUNT) taps_r++; }
     if (tx_n && all) {
         F3 Tn, Bn;
         onb(s.n, Tn, Bn);
-        const DTex tx = S.tex[tx_n - 1];
+        const DTex tx = texs[tx_n - 1];
         float4 r = tex4_any(tx, px, py);
         s.n = to_world(Tn, Bn, s.n, f3(r.x * 2.f - 1.f, r.y * 2.f - 1.f, r.z * 2.f - 1.f));
         if (COUNT) taps++;
@@ -819,7 +826,7 @@ PT_DEV float4 eval_envmap(const DScene& S, F3 dir)
     float theta = pt_acosf(clamp_(dir.y, -1.0f, 1.0f));
     float u = (PT_PI + pt_atan2f(dir.z, dir.x)) * PT_INV_TWO_PI;
     float v = theta * PT_INV_PI;
-    float4 r = tex4(S.env_rgba, S.env_w, S.env_h, u, v);
+    float4 r = tex4((const PT_GLOBAL float*)S.env_rgba, S.env_w, S.env_h, u, v);
     float pdf = disney::luminance(f3(r.x, r.y, r.z)) / S.env_sum;
     return make_float4(r.x, r.y, r.z, (pdf * S.env_w * S.env_h) / (PT_TWO_PI * PT_PI * pt_sinf(theta)));
 }
@@ -892,7 +899,7 @@ PT_DEV void env_search_texel(const DScene& S, float xi, uint32_t& taps_r, int& x
 PT_DEV float4 sample_envmap_texel(const DScene& S, int x, int y, F3& color)
 {
     F2 uv = {(float)x / (float)S.env_w, (float)y / (float)S.env_h};
-    float4 r = tex4(S.env_rgba, S.env_w, S.env_h, uv.x, uv.y);
+    float4 r = tex4((const PT_GLOBAL float*)S.env_rgba, S.env_w, S.env_h, uv.x, uv.y);
     color = f3(r.x, r.y, r.z);
     float pdf = disney::luminance(color) / S.env_sum;
     float phi = uv.x * PT_TWO_PI;

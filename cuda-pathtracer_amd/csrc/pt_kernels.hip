@@ -168,8 +168,8 @@ __global__ __launch_bounds__(256) void env_tables_kernel(const float* __restrict
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= w * h) return;
     int y = i / w, mid = i - y * w;
-    col_table[i] = tex1(cdf, w, h, (float)mid / (float)w, (float)y / (float)h);
-    if (mid == 0) row_table[y] = tex1(cdf, w, h, 1.f, (float)y / (float)h);
+    col_table[i] = tex1((const PT_GLOBAL float*)cdf, w, h, (float)mid / (float)w, (float)y / (float)h);
+    if (mid == 0) row_table[y] = tex1((const PT_GLOBAL float*)cdf, w, h, 1.f, (float)y / (float)h);
 }
 void launch_env_tables(const float* cdf_dev, int w, int h, float* row_table_dev, float* col_table_dev, hipStream_t stream)
 {

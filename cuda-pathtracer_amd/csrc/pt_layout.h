@@ -83,6 +83,7 @@ struct DScene {
                                   // triangle instead of after it, and the visibility walk reads the flag with one dependent load instead of two
     const DMat* mats;
     const DTex* tex;
+    int n_mats, n_tex;            // entries of the two tables
     const float* env_rgba;
     const float* env_cdf;
     const float* env_row_table;   // [H]   filtered CDF lookups of the row search (envmap_cuda.cu:33)

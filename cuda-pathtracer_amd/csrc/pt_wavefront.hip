@@ -948,10 +948,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTE
 #ifndef PT_PATHHIT_WAVES
 #define PT_PATHHIT_WAVES 4
 #endif
-template <bool COUNT>
+#ifndef PT_PATHHIT_TABLES
+#define PT_PATHHIT_TABLES 1
+#endif
+// TABLES: the material records and texture descriptors are copied to LDS first (scenes with at most kLocalMats
+// materials and kLocalTex textures): a lane's seven 16-byte reads of its material are then LDS reads instead of
+// seven gathers the wave sends through the texture addresser, which is what this kernel keeps busiest.
+constexpr int kLocalMats = 64, kLocalTex = 64;
+template <bool COUNT, bool TABLES>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_PATHHIT_WAVES))) void wf_pathhit_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
     __shared__ uint32_t counts[kStripes];
+    __shared__ float4 s_mats[TABLES ? kLocalMats * 8 : 1];
+    __shared__ DTex s_tex[TABLES ? kLocalTex : 1];
+    if (TABLES) {
+        for (int k = (int)threadIdx.x; k < S.n_mats * 8; k += kBlock) s_mats[k] = reinterpret_cast<const float4*>(S.mats)[k];
+        for (int k = (int)threadIdx.x; k < S.n_tex; k += kBlock) s_tex[k] = S.tex[k];
+        __syncthreads();
+    }
     BlockCursor bc = first_block(w.counters + WF_CTR_SEG_PATH, w.counters + WF_CTR_N_P, 1, counts);
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t nsamples = 0;
@@ -976,7 +990,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_PATHH
             P.so = P.sd = P.light = P.env_color = f3(0.f, 0.f, 0.f); P.env_pdf = 0.f;
             sample = unpack_core(pc0, pc1, pc2, w, P, id);
             Surf info;
-            resolve_hit<COUNT>(S, h, P.d, info, tl.taps, tl.taps_r, false);
+            resolve_hit<COUNT, TABLES>(S, h, P.d, info, tl.taps, tl.taps_r, false, nullptr, s_mats, s_tex);
             mat_bits = __int_as_float(S.tri_info ? (int)(S.tri_info[h.tri] & 0x7FFFFFFFu) : S.tri_ref[h.tri].matIndex);
             on_path_vertex<COUNT>(S, cam, P, info, tl);
             finished = P.state == ST_DONE;
@@ -1450,7 +1464,12 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
     // path hits: one kernel for scenes that draw light samples (its time is reported in the resolve stage's place and the
     // vertex stage's stays zero), resolve then vertex (with the bsdf stage inside) in sun/sky mode
     const bool fused = PT_FUSED_PATH_STAGE && S.sky_mode != PT_SKY_SUNSKY;
-    if (fused) PT_STAGE(wf_pathhit_kernel, 2, w, S, cam, ctr);
+    if (fused) {
+        const bool tables = S.n_mats <= kLocalMats && S.n_tex <= kLocalTex && PT_PATHHIT_TABLES;
+        if (tables) { if (ctr) hipLaunchKernelGGL((wf_pathhit_kernel<true, true>), stage, block, 0, s, w, S, cam, ctr); else hipLaunchKernelGGL((wf_pathhit_kernel<false, true>), stage, block, 0, s, w, S, cam, ctr); }
+        else { if (ctr) hipLaunchKernelGGL((wf_pathhit_kernel<true, false>), stage, block, 0, s, w, S, cam, ctr); else hipLaunchKernelGGL((wf_pathhit_kernel<false, false>), stage, block, 0, s, w, S, cam, ctr); }
+        if (ev) (void)hipEventRecord(ev[2], s);
+    }
     else PT_STAGE(wf_resolve_kernel, 2, w, S, ctr);
     // (before anything else appends to the next shadow queue)
     if (S.sky_mode == PT_SKY_SUNSKY) {
