@@ -36,18 +36,8 @@ import numpy as np  # noqa: E402
 N_SIMDS, CLOCK_GHZ = 1024, 2.4      # 256 CUs x 4 SIMDs; one wave64 vector instruction per SIMD every 4 cycles
 VALU_PEAK_GINST = N_SIMDS * CLOCK_GHZ / 4
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E datasheet peak
-STAGES = ('extend', 'resolve', 'vertex', 'miss', 'shadow', 'bsdf')      # the slots of pt_stage_times
-KERNEL_NAMES = {'extend': 'wf_extend_kernel', 'resolve': 'wf_resolve_kernel', 'vertex': 'wf_vertex_kernel', 'miss': 'wf_miss_kernel',
-                'shadow': 'wf_shadow_kernel', 'bsdf': 'wf_bsdf_kernel', 'path_hit': 'wf_pathhit_kernel'}
-
-
-def stage_kernels(sunsky):
-    """(name, slot of pt_stage_times) of the stage kernels an iteration launches. Scenes that draw light samples run both
-    halves of a path vertex in one kernel, timed in the resolve slot; sun/sky mode runs resolve and vertex (with the
-    bsdf stage inside) and has no shadow or bsdf launches that do work."""
-    if sunsky:
-        return [(n, n) for n in STAGES]
-    return [('extend', 'extend'), ('path_hit', 'resolve'), ('miss', 'miss'), ('shadow', 'shadow'), ('bsdf', 'bsdf')]
+STAGES = ('extend', 'path_hit', 'unused', 'miss', 'shadow', 'bsdf')      # the slots of pt_stage_times
+KERNEL_NAMES = {'extend': 'wf_extend_kernel', 'path_hit': 'wf_pathhit_kernel', 'miss': 'wf_miss_kernel', 'shadow': 'wf_shadow_kernel', 'bsdf': 'wf_bsdf_kernel'}
 
 
 def algorithmic_bytes(c):
@@ -75,10 +65,6 @@ def requested_bytes(c, packed_textures):
         # hit and path record in (64), shading triangle (112), material (128), texels; light sample: guide, column table, per-texel values (48);
         # out: a whole shadow record for a vertex with a light sample (160), a path record for a ray that passed through (48); misses listed (4)
         'path_hit': 64 * c['path_rays'] + (112 + 128) * hits + tap4 * material_taps + tap1 * c['tex_taps_r'] * 0.5 + (48 + 160) * env + 48 * max(hits - env, 0.0) + 4 * misses,
-        # the two-kernel form (sun/sky mode). resolve: hit and direction in (32), shading triangle (112), material (128), texels; link + vertex arrays out (64); misses listed (4)
-        'resolve': 32 * c['path_rays'] + (112 + 128 + 64) * hits + tap4 * material_taps + tap1 * c['tex_taps_r'] * 0.5 + 4 * misses,
-        # link, vertex arrays and path record in (112), the material's constants (64, from the caches); light sample: guide, column table, per-texel values (48); ray, path state, light out (112)
-        'vertex': (112 + 64 + 112) * hits + 48 * env,
         # list entry and path record in (52), four environment texels (64), a new camera ray out (48)
         'miss': (52 + 64 + 48) * misses,
         # direction, hit and state in (48), uv words of the shading triangle (32), material (128), alpha/metallic texels; state out (16), list entry (4)
@@ -346,7 +332,7 @@ def main():
             # the layout-independent accounting on the reference's binary walk
             ref_per_launch = (40 * loc['rays'] + 32 * loc['box_tests'] + 48 * loc['tri_tests']) / args.steps / launches
             alg_per_launch = own_per_launch if loc['wide_nodes'] > 0 else ref_per_launch
-            for name, slot in stage_kernels(args.workload == 'sunsky'):
+            for name, slot in [(n, n) for n in STAGES if n in KERNEL_NAMES]:
                 e = pmk.get(KERNEL_NAMES[name], {})
                 k_ms = ms_one[slot] / launches_one
                 req_launch = req[name] / args.steps / launches_one

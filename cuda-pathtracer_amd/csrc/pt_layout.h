@@ -139,7 +139,7 @@ struct WfShadowQueue {
     float4 *c0, *c1, *c2;           // path state as in the path queue (o is the vertex position)
     float4 *d0, *d1;                // (transmittance so far, light pdf) (light radiance, 0)
     float4 *e0, *e1, *e4;           // vertex context: what differs from hit to hit: (base colour, roughness) (emission, metallic) (shading normal, alpha); the
-                                    // material's other parameters are read from its record (so.w holds its index once the vertex stage has run, so.y before)
+                                    // material's other parameters are read from its record (so.w holds its index)
 };
 
 // Striped queues. One 32-bit word takes about 90 returning atomic adds per microsecond from the whole chip
@@ -174,8 +174,8 @@ enum : int {
     WF_CTR_TAIL_S = WF_CTR_TAIL_P + kStripes * kStripeWords,    // ... to the next shadow queue
     WF_CTR_TAIL_B = WF_CTR_TAIL_S + kStripes * kStripeWords,    // entries of the bsdf list
     WF_CTR_TAIL_M = WF_CTR_TAIL_B + kStripes * kStripeWords,    // entries of the miss list
-    WF_CTR_SEG_PATH = WF_CTR_TAIL_M + kStripes * kStripeWords,  // next block of the stripe a workgroup of the resolve stage takes
-    WF_CTR_SEG_VERTEX = WF_CTR_SEG_PATH + kStripes * kStripeWords,
+    WF_CTR_SEG_PATH = WF_CTR_TAIL_M + kStripes * kStripeWords,  // next block of the stripe a workgroup of the path-hit stage takes
+    WF_CTR_SEG_VERTEX = WF_CTR_SEG_PATH + kStripes * kStripeWords,          // (not in use)
     WF_CTR_SEG_MISS = WF_CTR_SEG_VERTEX + kStripes * kStripeWords,
     WF_CTR_SEG_SHADOW = WF_CTR_SEG_MISS + kStripes * kStripeWords,
     WF_CTR_SEG_BSDF = WF_CTR_SEG_SHADOW + kStripes * kStripeWords,

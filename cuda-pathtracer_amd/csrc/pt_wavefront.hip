@@ -807,156 +807,35 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
     flush_tally<COUNT>(ctr, tl, 0);
 }
 
-// ---------------------------------------------------------------- resolve
-// First half of a path vertex (what triangleIntersect does for the hit it keeps, pathtracer.cu:140-181): shading
-// normal and material values at the hit, up to five filtered texture lookups. It is a chain of dependent gathers
-// (hit -> triangle -> material -> texture -> texels) that needs the ray direction but nothing else of the sample,
-// so it runs as a kernel of its own with few registers and many waves per SIMD to hide the chain. Every hit gets
-// its position in the next shadow queue here, and the resolved surface is written straight into that record's
-// vertex arrays; the vertex stage fills in the rest. Rays that left the scene are listed for the miss stage.
-// (Launched in sun/sky mode, whose vertex kernel carries the bsdf stage; scenes with light samples run both halves in
-// wf_pathhit_kernel.)
-#ifndef PT_RESOLVE_WAVES
-#define PT_RESOLVE_WAVES 5      // (4: -1.7 % on the bench; 6 spills)
-#endif
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_RESOLVE_WAVES))) void wf_resolve_kernel(WfParams w, DScene S, DCounters* ctr)
-{
-    __shared__ uint32_t counts[kStripes];
-    BlockCursor bc = first_block(w.counters + WF_CTR_SEG_PATH, w.counters + WF_CTR_N_P, 1, counts);
-    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (;;) {
-        const uint32_t blk = next_block(w.counters + WF_CTR_SEG_PATH, counts, bc);
-        if (blk == kNone) break;                    // uniform over the workgroup
-        const uint32_t stripe = blk & (uint32_t)(kStripes - 1);
-        const uint32_t i = blk * kBlock + threadIdx.x;
-        const bool have = threadIdx.x < block_fill(blk, counts);
-        Hit h; h.t = 0.f; h.tri = PT_NO_TRI; h.u = 0.f; h.v = 0.f;
-        if (have) { float4 h4 = w.hitP[i]; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w; }
-        const bool hit = have && h.tri != PT_NO_TRI;
-        Surf info;
-        int mat_index = 0;
-        if (hit) {
-            float4 d4 = w.Pc.c1[i];
-            resolve_hit<COUNT>(S, h, f3(d4.x, d4.y, d4.z), info, tl.taps, tl.taps_r, false);
-            info.m.rough = pt_fmaxf(info.m.rough, 0.0001f);         // pathtracer.cu:427
-            mat_index = S.tri_info ? (int)(S.tri_info[h.tri] & 0x7FFFFFFFu) : S.tri_ref[h.tri].matIndex;
-        }
-        Appends a;
-        a.want[0] = hit; a.tail[0] = w.counters + WF_CTR_TAIL_S;
-        a.want[1] = have && !hit; a.tail[1] = w.counters + WF_CTR_TAIL_M;
-        reserve<2>(a, stripe);
-        if (hit) {
-            const uint32_t j = a.pos[0];
-            const Mat& m = info.m;
-            // (hit distance, material, -, path record): what the vertex stage needs beside the vertex arrays
-            w.Sn.so[j] = make_float4(h.t, __int_as_float(mat_index), 0.f, __uint_as_float(i));
-            w.Sn.e0[j] = make_float4(m.base.x, m.base.y, m.base.z, m.rough);
-            w.Sn.e1[j] = make_float4(m.emis.x, m.emis.y, m.emis.z, m.metal);
-            w.Sn.e4[j] = make_float4(info.n.x, info.n.y, info.n.z, m.alpha);
-        }
-        if (a.want[1]) w.miss_list[a.pos[1]] = i;
-    }
-    flush_tally<COUNT>(ctr, tl, 0);
-}
-
-// ---------------------------------------------------------------- vertex
-// Second half of a path vertex (pathtracer.cu:426-481) for the records the resolve stage placed in the next shadow
-// queue: medium event, alpha test, light-sample set-up. A vertex that drew a light sample completes its record
-// where it is; a ray that passed through the surface moves on to the next path queue and leaves a dead record.
-#ifndef PT_VERTEX_WAVES
-#define PT_VERTEX_WAVES 4       // (5 spills 24 registers, 250 in the sun/sky variant: -1.5 % on the bench, -14 % on the sun/sky scene; 3: the same as 4)
-#endif
+// ---------------------------------------------------------------- path hit
+// A path vertex (pathtracer.cu:140-181 for the hit the traversal kept, then :426-481) for every record of the path
+// queue whose ray hit a surface: shading normal and material values at the hit with up to five filtered texture
+// lookups (a chain of dependent gathers: hit -> triangle -> material -> texture -> texels), medium event, alpha test,
+// light-sample set-up. A vertex that drew a light sample takes a record of the next shadow queue; a ray that passed
+// through the surface moves on to the next path queue; rays that left the scene are listed for the miss stage. The
+// path record is fetched beside the hit, not after it.
+// The two halves were kernels of their own at first (the gathers at five waves per SIMD, the rest at four, the
+// resolved surface handed over through the record): one kernel on the state in registers is 2.1 % faster on the bench
+// at four waves per SIMD (128 registers; the same as the two kernels at three, 112 spilled registers at five).
 // DIRECT: for scenes that draw no light samples (sun/sky mode). The vertex has no visibility walk to wait for, so
-// its bsdf stage (after_light) runs here, on the state in registers, instead of going through a shadow-queue record.
-template <bool COUNT, bool DIRECT>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_VERTEX_WAVES))) void wf_vertex_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
-{
-    // the records the resolve stage allocated; nothing else has appended yet
-    __shared__ uint32_t s_counts[kStripes];
-    BlockCursor bc = first_block(w.counters + WF_CTR_SEG_VERTEX, w.counters + WF_CTR_TAIL_S, kStripeWords, s_counts);
-    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t nsamples = 0;
-    for (;;) {
-        const uint32_t blk = next_block(w.counters + WF_CTR_SEG_VERTEX, s_counts, bc);
-        if (blk == kNone) break;
-        const uint32_t stripe = blk & (uint32_t)(kStripes - 1);
-        const uint32_t j = blk * kBlock + threadIdx.x;
-        const bool have = threadIdx.x < block_fill(blk, s_counts);
-        Path P;
-        SampleId id = {0, 0, 0, 0u, 0u};
-        uint32_t sample = kNone;
-        P.state = ST_DONE;
-        bool finished = false;
-        float mat_bits = 0.f;
-        if (have) {
-            const float4 link = w.Sn.so[j];
-            mat_bits = link.y;
-            const float4 a = w.Sn.e0[j], b = w.Sn.e1[j], e = w.Sn.e4[j];
-            sample = load_path(w.Pc, __float_as_uint(link.w), w, P, id);
-            Surf info;
-            info.t = link.x; info.hit = true; info.inside = false;
-            Mat& m = info.m;
-            m.base = f3(a.x, a.y, a.z); m.rough = a.w;
-            m.emis = f3(b.x, b.y, b.z); m.metal = b.w;
-            material_constants(S, __float_as_int(link.y), m);
-            info.n = f3(e.x, e.y, e.z); m.alpha = e.w;
-            m.sigA = f3(0.f, 0.f, 0.f); m.sigS = f3(0.f, 0.f, 0.f);
-            if (P.inside) {         // the medium this path travels in is described by the surface it meets (pathtracer.cu:432-433)
-                const DMat& M = S.mats[__float_as_int(link.y)];
-                m.sigA = f3(M.sigA[0], M.sigA[1], M.sigA[2]); m.sigS = f3(M.sigS[0], M.sigS[1], M.sigS[2]);
-            }
-            on_path_vertex<COUNT>(S, cam, P, info, tl);
-            if (DIRECT && P.state == ST_AFTER) after_light<COUNT>(S, cam, P, tl);
-            finished = P.state == ST_DONE;
-        }
-        finish_and_regenerate<COUNT>(w, cam, P, sample, id, finished, nsamples);
-        // where the sample goes: a new or passed-through path ray to the next path queue; a vertex with its light sample
-        // stays in this record, and, when there is no visibility walk to wait for (sun/sky mode draws no light sample),
-        // goes straight onto this iteration's bsdf list as well
-        const bool alive = have && P.state != ST_DONE;
-        const bool stays = alive && P.state != ST_PATH;
-        Appends ap;
-        ap.want[0] = alive && P.state == ST_PATH; ap.tail[0] = w.counters + WF_CTR_TAIL_P;
-        ap.want[1] = alive && P.state == ST_AFTER; ap.tail[1] = w.counters + WF_CTR_TAIL_B;
-        reserve<2>(ap, stripe);
-        if (ap.want[0]) store_path(w.Pn, ap.pos[0], P, sample);
-        if (stays) {
-            w.Sn.so[j] = make_float4(P.so.x, P.so.y, P.so.z, mat_bits);       // (the material index rides with the walk's origin)
-            w.Sn.sd[j] = make_float4(P.sd.x, P.sd.y, P.sd.z, __int_as_float(P.state == ST_SHADOW ? 1 : 0));
-            store_core(w.Sn.c0, w.Sn.c1, w.Sn.c2, j, P, sample);
-            w.Sn.d0[j] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
-            w.Sn.d1[j] = make_float4(P.env_color.x, P.env_color.y, P.env_color.z, 0.f);
-        } else if (have && !DIRECT) {
-            w.Sn.sd[j] = make_float4(0.f, 0.f, 0.f, __int_as_float(0));       // a dead record: no ray, no sample
-        }
-        if (ap.want[1]) w.bsdf_list[ap.pos[1]] = j | 0x80000000u;
-    }
-    flush_tally<COUNT>(ctr, tl, nsamples);
-}
-
-// ---------------------------------------------------------------- path hit (resolve and vertex in one kernel)
-// Both halves of a path vertex on the state in registers, for scenes that draw light samples: the resolved surface
-// never travels through the record (64 bytes written and read back per hit in the two-kernel form), a record of the
-// next shadow queue is taken only by a vertex that drew a light sample, and the path record is fetched with the hit,
-// not after it. Four waves per SIMD (128 registers): +2.1 % on the bench against the two kernels; at three the same as
-// the two kernels, at five 112 spilled registers. -DPT_FUSED_PATH_STAGE=0 selects the two kernels for comparison; the
-// sun/sky mode always uses them (its vertex kernel carries the bsdf stage, which does not fit beside the resolve half).
-#ifndef PT_FUSED_PATH_STAGE
-#define PT_FUSED_PATH_STAGE 1
-#endif
+// its bsdf stage (after_light) runs here as well and no shadow record is written: three waves per SIMD (168
+// registers, 29 spilled; 152 spilled at four: -4 %), 10 % faster on the sun/sky scene than resolve and vertex + bsdf
+// as two kernels.
+// TABLES: the material records and texture descriptors are copied to LDS first (scenes with at most kLocalMats
+// materials and kLocalTex textures): a lane's seven 16-byte reads of its material are then LDS reads instead of
+// seven gathers the wave sends through the texture addresser, which this kernel keeps busy for 0.7 of its time (+0.8 %).
 #ifndef PT_PATHHIT_WAVES
 #define PT_PATHHIT_WAVES 4
+#endif
+#ifndef PT_PATHHIT_DIRECT_WAVES
+#define PT_PATHHIT_DIRECT_WAVES 3
 #endif
 #ifndef PT_PATHHIT_TABLES
 #define PT_PATHHIT_TABLES 1
 #endif
-// TABLES: the material records and texture descriptors are copied to LDS first (scenes with at most kLocalMats
-// materials and kLocalTex textures): a lane's seven 16-byte reads of its material are then LDS reads instead of
-// seven gathers the wave sends through the texture addresser, which is what this kernel keeps busiest.
 constexpr int kLocalMats = 64, kLocalTex = 64;
-template <bool COUNT, bool TABLES>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_PATHHIT_WAVES))) void wf_pathhit_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+template <bool COUNT, bool TABLES, bool DIRECT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DIRECT ? PT_PATHHIT_DIRECT_WAVES : PT_PATHHIT_WAVES))) void wf_pathhit_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
     __shared__ uint32_t counts[kStripes];
     __shared__ float4 s_mats[TABLES ? kLocalMats * 8 : 1];
@@ -993,6 +872,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_PATHH
             resolve_hit<COUNT, TABLES>(S, h, P.d, info, tl.taps, tl.taps_r, false, nullptr, s_mats, s_tex);
             mat_bits = __int_as_float(S.tri_info ? (int)(S.tri_info[h.tri] & 0x7FFFFFFFu) : S.tri_ref[h.tri].matIndex);
             on_path_vertex<COUNT>(S, cam, P, info, tl);
+            if (DIRECT && P.state == ST_AFTER) after_light<COUNT>(S, cam, P, tl);      // (no light sample to wait for: the bsdf stage runs here)
             finished = P.state == ST_DONE;
         }
         finish_and_regenerate<COUNT>(w, cam, P, sample, id, finished, nsamples);
@@ -1085,7 +965,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
         // has any still waits for its hit, and the chain of dependent loads is one shorter)
         float4 sd4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = sd4, c2_in = sd4;
         if (in_block) { sd4 = w.Sc.sd[i]; h4 = w.hitS[i]; c2_in = w.Sc.c2[i]; }
-        // a record without a pending ray was handed to the bsdf stage when it was written (see wf_vertex_kernel)
+        // (every record of the queue carries a pending ray, marked in sd.w; the check guards the material index behind it)
         const bool have = in_block && __float_as_int(sd4.w) != 0;
         Path P;
         P.state = ST_DONE; P.lobes = 0; P.nee_surface = false; P.nee_skip = false;
@@ -1217,9 +1097,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_BSDF_
         P.state = ST_DONE;
         bool finished = false;
         if (have) {
-            const uint32_t e = w.bsdf_list[k];
-            if (e >> 31) sample = load_shadow(w.Sn, e & 0x7FFFFFFFu, w, S, P, id);
-            else sample = load_shadow(w.Sc, e, w, S, P, id);
+            sample = load_shadow(w.Sc, w.bsdf_list[k], w, S, P, id);
             after_light<COUNT>(S, cam, P, tl);
             finished = P.state == ST_DONE;
         }
@@ -1287,8 +1165,7 @@ __global__ __launch_bounds__(kBlock) void wf_drain_kernel(WfParams w, DScene S, 
     if (have) {
         if (!from_shadow) load_path(w.Pc, q, w, P, id);
         else {
-            // a record without a pending ray already went through the bsdf stage (its sample lives on elsewhere) or was
-            // left dead by the vertex stage, whose so.w is then not a material index: it is not loaded
+            // (a record without a pending ray, sd.w == 0, holds no material index to follow: none is written at present)
             if (__float_as_int(w.Sc.sd[q].w) == 0) have = false;
             else load_shadow(w.Sc, q, w, S, P, id);
         }
@@ -1461,21 +1338,15 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
 #define PT_STAGE(kernel, k, ...) do { \
         if (ctr) hipLaunchKernelGGL(kernel<true>, stage, block, 0, s, __VA_ARGS__); else hipLaunchKernelGGL(kernel<false>, stage, block, 0, s, __VA_ARGS__); \
         if (ev) (void)hipEventRecord(ev[k], s); } while (0)
-    // path hits: one kernel for scenes that draw light samples (its time is reported in the resolve stage's place and the
-    // vertex stage's stays zero), resolve then vertex (with the bsdf stage inside) in sun/sky mode
-    const bool fused = PT_FUSED_PATH_STAGE && S.sky_mode != PT_SKY_SUNSKY;
-    if (fused) {
+    // path hits (timed in the place of the stage's first half; the second half's slot stays zero)
+    {
+        const bool direct = S.sky_mode == PT_SKY_SUNSKY;
         const bool tables = S.n_mats <= kLocalMats && S.n_tex <= kLocalTex && PT_PATHHIT_TABLES;
-        if (tables) { if (ctr) hipLaunchKernelGGL((wf_pathhit_kernel<true, true>), stage, block, 0, s, w, S, cam, ctr); else hipLaunchKernelGGL((wf_pathhit_kernel<false, true>), stage, block, 0, s, w, S, cam, ctr); }
-        else { if (ctr) hipLaunchKernelGGL((wf_pathhit_kernel<true, false>), stage, block, 0, s, w, S, cam, ctr); else hipLaunchKernelGGL((wf_pathhit_kernel<false, false>), stage, block, 0, s, w, S, cam, ctr); }
+#define PT_PATHHIT(C, T, D) hipLaunchKernelGGL((wf_pathhit_kernel<C, T, D>), stage, block, 0, s, w, S, cam, ctr)
+        if (direct) { if (tables) { if (ctr) PT_PATHHIT(true, true, true); else PT_PATHHIT(false, true, true); } else { if (ctr) PT_PATHHIT(true, false, true); else PT_PATHHIT(false, false, true); } }
+        else { if (tables) { if (ctr) PT_PATHHIT(true, true, false); else PT_PATHHIT(false, true, false); } else { if (ctr) PT_PATHHIT(true, false, false); else PT_PATHHIT(false, false, false); } }
+#undef PT_PATHHIT
         if (ev) (void)hipEventRecord(ev[2], s);
-    }
-    else PT_STAGE(wf_resolve_kernel, 2, w, S, ctr);
-    // (before anything else appends to the next shadow queue)
-    if (S.sky_mode == PT_SKY_SUNSKY) {
-        if (ctr) hipLaunchKernelGGL((wf_vertex_kernel<true, true>), stage, block, 0, s, w, S, cam, ctr); else hipLaunchKernelGGL((wf_vertex_kernel<false, true>), stage, block, 0, s, w, S, cam, ctr);
-    } else if (!fused) {
-        if (ctr) hipLaunchKernelGGL((wf_vertex_kernel<true, false>), stage, block, 0, s, w, S, cam, ctr); else hipLaunchKernelGGL((wf_vertex_kernel<false, false>), stage, block, 0, s, w, S, cam, ctr);
     }
     if (ev) (void)hipEventRecord(ev[3], s);
     PT_STAGE(wf_miss_kernel, 4, w, S, cam, ctr);

@@ -392,10 +392,10 @@ class Renderer:
         return ms.value, n.value
 
     def stage_times(self):
-        """({kernel: ms}, iterations) accumulated since stage timing was switched on (extend, resolve, vertex, miss, shadow, bsdf)."""
+        """({kernel: ms}, iterations) accumulated since stage timing was switched on (extend, path_hit, a slot not in use, miss, shadow, bsdf)."""
         ms, n = (C.c_double * 6)(), C.c_uint64()
         check(lib().pt_stage_times(self.h, ms, C.byref(n)))
-        return dict(zip(('extend', 'resolve', 'vertex', 'miss', 'shadow', 'bsdf'), list(ms))), n.value
+        return dict(zip(('extend', 'path_hit', 'unused', 'miss', 'shadow', 'bsdf'), list(ms))), n.value
 
     def scene_bytes(self):
         a, b = C.c_uint64(), C.c_uint64()

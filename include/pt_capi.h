@@ -235,7 +235,7 @@ int pt_reset_counters(pt_ctx* ctx);
 int pt_enable_counters(pt_ctx* ctx, int on);                            /* instrumented kernels (slower); off by default. 1: the reference-order binary walk is traced and its box and triangle tests counted (equal to the reference's counts, pathtracer.cu:207,230); 2: the production walk over the wide nodes is traced and its own node visits and triangle tests counted (wide_nodes, wide_tris) */
 int pt_stage_timing(pt_ctx* ctx, int on, double* extend_ms_out, uint64_t* extend_launches_out); /* HIP-event time of the extend kernel: returns the totals since the last call, then switches timing on/off and clears them */
 #define PT_STAGE_KERNELS 6
-int pt_stage_times(pt_ctx* ctx, double* ms_out, uint64_t* iterations_out);  /* HIP-event times of the stage kernels accumulated since timing was last switched on: ms_out[PT_STAGE_KERNELS] = extend, resolve, vertex, miss, shadow, bsdf (scenes with an environment map run resolve and vertex as one kernel, whose time is in resolve's place with vertex at zero; on the launch streams; with two lanes the kernels of one lane run beside the other's, so the durations do not add up to wall time) and the stage iterations they cover; call before pt_stage_timing clears them */
+int pt_stage_times(pt_ctx* ctx, double* ms_out, uint64_t* iterations_out);  /* HIP-event times of the stage kernels accumulated since timing was last switched on: ms_out[PT_STAGE_KERNELS] = extend, path hit, (not in use: zero), miss, shadow, bsdf (on the launch streams; with two lanes the kernels of one lane run beside the other's, so the durations do not add up to wall time) and the stage iterations they cover; call before pt_stage_timing clears them */
 int pt_debug_words(pt_ctx* ctx, unsigned long long* out16);                 /* diagnostic builds only: 16 statistics words of the traversal kernel, zeroed on read (all zero in a regular build) */
 int pt_scene_bytes(pt_ctx* ctx, uint64_t* node_bytes, uint64_t* tri_bytes); /* bytes of the nodes the production traversal walks (4-wide, or quantized binary) and of the leaf-ordered triangle records */
 int pt_detmath_probe(pt_ctx* ctx, const float* x, const float* y, int n, float* out12); /* device evaluation of include/pt_detmath.h, 12 results per input pair */

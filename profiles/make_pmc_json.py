@@ -12,7 +12,7 @@ import re
 import sys
 
 HBM_PEAK = 8.0e12
-KERNELS = ['wf_extend_kernel', 'wf_pathhit_kernel', 'wf_resolve_kernel', 'wf_vertex_kernel', 'wf_miss_kernel', 'wf_shadow_kernel', 'wf_bsdf_kernel']
+KERNELS = ['wf_extend_kernel', 'wf_pathhit_kernel', 'wf_miss_kernel', 'wf_shadow_kernel', 'wf_bsdf_kernel']
 
 
 def timed_variant(line, kernel):
@@ -99,7 +99,7 @@ def main():
         'soup': entry(d, 'soup_', [1920, 1080, 16, 512], tag,
                       'The 0.8 GB of wide nodes and triangle records fit no cache, but the upper levels of the tree do: a little over half of the bytes asked for reach the memory side.'),
         'sunsky': entry(d, 'sunsky_', [1920, 1080, 64, 16], tag,
-                        'Sun/sky mode draws no light samples: there is no shadow stage, and the bsdf stage runs inside the vertex kernel.'),
+                        'Sun/sky mode draws no light samples: there is no shadow stage, and the bsdf stage runs inside the path-hit kernel.'),
     }
     with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'pmc_traffic.json'), 'w') as f:
         json.dump(out, f, indent=1)
