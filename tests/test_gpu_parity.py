@@ -196,6 +196,35 @@ def test_sun_sky_mode_glossy_dielectric(mode):
     assert ctr['rays'] == st['rays']
 
 
+@pytest.mark.parametrize('sky_mode', [pytest.param(0, id='environment_map'), pytest.param(1, id='sun_sky')])
+def test_material_table_larger_than_the_kernels_local_copy(sky_mode):
+    """The path-hit kernel keeps up to 64 materials and 64 textures in LDS; a scene with more takes the variant that
+    reads them from memory. The atrium with its 25 materials listed three times, every triangle moved to one of the three
+    copies of its material, is the same scene: same accumulators and counters as with the table of 25."""
+    if sky_mode:
+        b = util.atrium(detail=0.3, env_size=(64, 32), glossy=0.3, glass=0.2, sky_mode=1)
+        P, bounces = scenes.atrium_params(ptamd.default_params(64, 40)), 16
+    else:
+        b = util.atrium(detail=0.35, env_size=(256, 128))
+        P, bounces = scenes.atrium_params(ptamd.default_params(96, 56)), 512
+    n = len(b.mats)
+    assert n <= 64 < 3 * n
+    tris = b.tris.copy()
+    tris['matIndex'] = b.tris['matIndex'] + n * (np.arange(len(tris)) % 3)
+    big = util.Bundle(tris, np.concatenate([b.mats, b.mats, b.mats]), b.textures, b.env, b.sky_mode)
+    assert np.array_equal(big.idx, b.idx)
+    out = []
+    for bundle in (b, big):
+        r = bundle.renderer(P)
+        r.set_max_bounces(bounces)
+        r.enable_counters(True)
+        r.render(P, 0, 2)
+        out.append((r.read_accum(), r.counters()))
+        r.close()
+    assert np.array_equal(bits(out[0][0]), bits(out[1][0])) and out[0][0].sum() > 0
+    assert {k: v for k, v in out[0][1].items() if k != 'last_ms'} == {k: v for k, v in out[1][1].items() if k != 'last_ms'}
+
+
 @pytest.mark.parametrize('pool', [(64, 1), (320, 3), (320, 2), (512, 5), (1 << 14, 64)])
 def test_wavefront_pool_size_does_not_change_results(pool):
     """Tiny pools force slot regeneration, retirement and several staging chunks; odd image size
