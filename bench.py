@@ -63,14 +63,14 @@ def requested_bytes(c, packed_textures):
         # both queues: origin + direction in (32), hit out (16); 64 per wide node visited, 48 per triangle tested
         'extend': 48 * c['rays'] + 64 * c['wide_nodes'] + 48 * c['wide_tris'],
         # hit and path record in (64), shading triangle (112), material (128), texels; light sample: guide, column table, per-texel values (48);
-        # out: a whole shadow record for a vertex with a light sample (160), a path record for a ray that passed through (48); misses listed (4)
-        'path_hit': 64 * c['path_rays'] + (112 + 128) * hits + tap4 * material_taps + tap1 * c['tex_taps_r'] * 0.5 + (48 + 160) * env + 48 * max(hits - env, 0.0) + 4 * misses,
+        # out: a whole shadow record for a vertex with a light sample (128), a path record for a ray that passed through (48); misses listed (4)
+        'path_hit': 64 * c['path_rays'] + (112 + 128) * hits + tap4 * material_taps + tap1 * c['tex_taps_r'] * 0.5 + (48 + 128) * env + 48 * max(hits - env, 0.0) + 4 * misses,
         # list entry and path record in (52), four environment texels (64), a new camera ray out (48)
         'miss': (52 + 64 + 48) * misses,
         # direction, hit and state in (48), uv words of the shading triangle (32), material (128), alpha/metallic texels; state out (16), list entry (4)
         'shadow': (48 + 32 + 128 + 20) * segments + tap1 * c['tex_taps_r'] * 0.5,
-        # list entry and whole record in (164), the material's constants (64, from the caches), continuing path out (48)
-        'bsdf': (164 + 64 + 48) * hits,
+        # list entry and whole record in (132), the material's constants (96, from the caches), continuing path out (48)
+        'bsdf': (132 + 96 + 48) * hits,
     }
 
 

@@ -461,7 +461,7 @@ struct Mat {
     float rough, aniso, metal, subsurf, sheen, coat, coat_rough, strans, alpha, ior;
     float G; F3 sigA, sigS;
 };
-struct Surf { float t; F3 n; Mat m; bool hit; bool inside; };
+struct Surf { float t; F3 n; Mat m; bool hit; bool inside; bool emis_map; };      // emis_map: the emission came out of a texture map
 
 PT_DEV void default_mat(Mat& m)          // structs.cuh:75-94
 {
@@ -492,7 +492,7 @@ PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& 
     // the medium only (pathtracer.cu:279-295): the roughness, emission and normal maps are not fetched (the counting
     // build fetches them, as the reference does, so its tap counts stay the reference's)
     const bool all = COUNT || !visibility_only;
-    s.t = h.t; s.hit = h.tri != PT_NO_TRI; s.inside = false; s.n = f3(0, 0, 0);
+    s.t = h.t; s.hit = h.tri != PT_NO_TRI; s.inside = false; s.n = f3(0, 0, 0); s.emis_map = false;
     default_mat(s.m);
     if (!s.hit) return;
     const pt_triangle* T = S.tri_ref + h.tri;
@@ -533,7 +533,7 @@ PT_DEV void resolve_hit(const DScene& S, const Hit& h, F3 d, Surf& s, uint32_t& 
     PT_MARK(marks, 3);
     if (tx_r && all) { const DTex tx = texs[tx_r - 1]; s.m.rough = tex1_any(tx, px, py); if (COUNT) taps_r++; }
     if (tx_m) { const DTex tx = texs[tx_m - 1]; s.m.metal = tex1_any(tx, px, py); if (COUNT) taps_r++; }
-    if (tx_e && all) { const DTex tx = texs[tx_e - 1]; float r = tex1_any(tx, px, py); s.m.emis = f3(r, r, r); if (COUNT) taps_r++; }
+    if (tx_e && all) { const DTex tx = texs[tx_e - 1]; float r = tex1_any(tx, px, py); s.m.emis = f3(r, r, r); s.emis_map = true; if (COUNT) taps_r++; }
     if (tx_n && all) {
         F3 Tn, Bn;
         onb(s.n, Tn, Bn);

@@ -135,11 +135,14 @@ struct DCounters {
 // are consecutive and of one kind whatever the paths did before.
 struct WfPathQueue { float4 *c0, *c1, *c2; };                  // (o, thr) (d, pdf) (result, flags + bounce, draws, sample id)
 struct WfShadowQueue {
-    float4 *so, *sd;                // pending segment of the visibility walk; sd.w != 0 while the record waits for its hit
-    float4 *c0, *c1, *c2;           // path state as in the path queue (o is the vertex position)
-    float4 *d0, *d1;                // (transmittance so far, light pdf) (light radiance, 0)
-    float4 *e0, *e1, *e4;           // vertex context: what differs from hit to hit: (base colour, roughness) (emission, metallic) (shading normal, alpha); the
-                                    // material's other parameters are read from its record (so.w holds its index)
+    float4 *so, *sd;                // pending segment of the visibility walk; so.w: the vertex's material; sd.w: 1 while the record waits for
+                                    // its hit, 2 when d0 holds the walk's transmittance as well
+    float4 *c0, *c1, *c2;           // path state as in the path queue (o is the vertex position), with the vertex's metallic value in the place
+                                    // of the last bounce's pdf, which nothing reads at a vertex (pathtracer.cu:449-480 set the next)
+    float4 *d0, *d1;                // (transmittance so far, -): written by a walk's first segment that crosses a medium, (1, 1, 1) otherwise;
+                                    // (light radiance, light pdf)
+    float4 *e0, *e1, *e4;           // vertex context, what differs from hit to hit: (base colour, roughness), (emission, -) only where the material
+                                    // has an emission map, (shading normal, alpha); the material's other parameters are read from its record
 };
 
 // Striped queues. One 32-bit word takes about 90 returning atomic adds per microsecond from the whole chip

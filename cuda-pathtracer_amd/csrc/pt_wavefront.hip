@@ -128,27 +128,32 @@ PT_DEV uint32_t load_path(const WfPathQueue& q, uint32_t i, const WfParams& w, P
     return load_core(q.c0, q.c1, q.c2, i, w, P, id);
 }
 // A whole record of the shadow queue. The record carries the values of the vertex that differ from hit to hit (what
-// the texture maps and the shading normal give: e0, e1, e4) and the index of its material (so.w); the material's other
-// parameters, which no map changes (resolve_hit), are read from its record, which stays in the caches.
-PT_DEV void material_constants(const DScene& S, int mat_index, Mat& m)
+// the texture maps and the shading normal give: e0, e4, the metallic value, and e1 where the material has an emission
+// map) and the index of its material (so.w); the material's other parameters, which no map changes (resolve_hit), are
+// read from its record, which stays in the caches. Returns whether the material has an emission map.
+PT_DEV bool material_constants(const DScene& S, int mat_index, Mat& m)
 {
     const float4* mq = reinterpret_cast<const float4*>(S.mats + mat_index);
-    const float4 m1 = mq[1], m2 = mq[2], m3 = mq[3], m4 = mq[4];
+    const float4 m0 = mq[0], m1 = mq[1], m2 = mq[2], m3 = mq[3], m4 = mq[4], m6 = mq[6];
+    m.emis = f3(m0.w, m1.x, m1.y);
     m.aniso = m1.w; m.subsurf = m2.y; m.sheen = m2.z; m.coat = m2.w;
     m.coat_rough = m3.x; m.strans = m3.y; m.ior = m3.w; m.G = m4.x;
+    return __float_as_int(m6.z) != 0;
 }
 PT_DEV uint32_t load_shadow(const WfShadowQueue& q, uint32_t i, const WfParams& w, const DScene& S, Path& P, SampleId& id)
 {
-    float4 so = q.so[i], sd = q.sd[i], l0 = q.d0[i], l1 = q.d1[i];
-    float4 a = q.e0[i], b = q.e1[i], e = q.e4[i];
+    float4 so = q.so[i], sd = q.sd[i], l1 = q.d1[i];
+    float4 a = q.e0[i], e = q.e4[i];
     uint32_t sample = load_core(q.c0, q.c1, q.c2, i, w, P, id);
     P.so = f3(so.x, so.y, so.z); P.sd = f3(sd.x, sd.y, sd.z);
-    P.light = f3(l0.x, l0.y, l0.z); P.env_pdf = l0.w;
-    P.env_color = f3(l1.x, l1.y, l1.z);
+    // the transmittance of the walk so far is (1, 1, 1) unless a segment crossed a medium (marked in sd.w)
+    P.light = f3(1.f, 1.f, 1.f);
+    if (__float_as_int(sd.w) == 2) { const float4 l0 = q.d0[i]; P.light = f3(l0.x, l0.y, l0.z); }
+    P.env_color = f3(l1.x, l1.y, l1.z); P.env_pdf = l1.w;
     Mat& m = P.vm;
     m.base = f3(a.x, a.y, a.z); m.rough = a.w;
-    m.emis = f3(b.x, b.y, b.z); m.metal = b.w;
-    material_constants(S, __float_as_int(so.w), m);
+    m.metal = P.pdf;            // (a vertex record keeps the metallic value where the last bounce's pdf was: that pdf is dead here, after_light sets the next)
+    if (material_constants(S, __float_as_int(so.w), m)) { const float4 b = q.e1[i]; m.emis = f3(b.x, b.y, b.z); }
     P.vn = f3(e.x, e.y, e.z); m.alpha = e.w;
     m.sigA = f3(0.f, 0.f, 0.f); m.sigS = f3(0.f, 0.f, 0.f);     // not used after the vertex
     return sample;
@@ -863,6 +868,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DIRECT ?
         P.state = ST_DONE;
         bool finished = false;
         float mat_bits = 0.f;
+        bool emis_map = false;
         float4 pc0, pc1, pc2;           // (fetched beside the hit: one dependent load less; the one ray in six that misses pays 48 bytes for nothing)
         if (have) { pc0 = w.Pc.c0[i]; pc1 = w.Pc.c1[i]; pc2 = w.Pc.c2[i]; }
         if (hit) {
@@ -871,6 +877,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DIRECT ?
             Surf info;
             resolve_hit<COUNT, TABLES>(S, h, P.d, info, tl.taps, tl.taps_r, false, nullptr, s_mats, s_tex);
             mat_bits = __int_as_float(S.tri_info ? (int)(S.tri_info[h.tri] & 0x7FFFFFFFu) : S.tri_ref[h.tri].matIndex);
+            emis_map = info.emis_map;
             on_path_vertex<COUNT>(S, cam, P, info, tl);
             if (DIRECT && P.state == ST_AFTER) after_light<COUNT>(S, cam, P, tl);      // (no light sample to wait for: the bsdf stage runs here)
             finished = P.state == ST_DONE;
@@ -886,13 +893,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DIRECT ?
         if (a.want[1]) {
             const uint32_t j = a.pos[1];
             const Mat& m = P.vm;
+            // 128 bytes: the walk's first segment (its transmittance starts at (1, 1, 1): sd.w = 1 says that d0 holds nothing yet),
+            // the path state with the vertex's metallic value in the place of the last bounce's pdf (dead at a vertex), the light
+            // sample, and what the maps gave; the emission only where it came out of a map
+            const float metal = m.metal;
             w.Sn.so[j] = make_float4(P.so.x, P.so.y, P.so.z, mat_bits);
             w.Sn.sd[j] = make_float4(P.sd.x, P.sd.y, P.sd.z, __int_as_float(1));
+            P.pdf = metal;
             store_core(w.Sn.c0, w.Sn.c1, w.Sn.c2, j, P, sample);
-            w.Sn.d0[j] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
-            w.Sn.d1[j] = make_float4(P.env_color.x, P.env_color.y, P.env_color.z, 0.f);
+            w.Sn.d1[j] = make_float4(P.env_color.x, P.env_color.y, P.env_color.z, P.env_pdf);
             w.Sn.e0[j] = make_float4(m.base.x, m.base.y, m.base.z, m.rough);
-            w.Sn.e1[j] = make_float4(m.emis.x, m.emis.y, m.emis.z, m.metal);
+            if (emis_map) w.Sn.e1[j] = make_float4(m.emis.x, m.emis.y, m.emis.z, 0.f);
             w.Sn.e4[j] = make_float4(P.vn.x, P.vn.y, P.vn.z, m.alpha);
         }
         if (a.want[2]) w.miss_list[a.pos[2]] = i;
@@ -971,15 +982,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
         P.state = ST_DONE; P.lobes = 0; P.nee_surface = false; P.nee_skip = false;
         P.light = f3(1.f, 1.f, 1.f); P.env_pdf = 0.f;
         float4 c2 = sd4;
-        // The transmittance (d0) is read only by the few walks that can change it: those inside a medium now, or that
-        // left one earlier (sd.w == 2). For every other walk it is still the (1, 1, 1) its vertex wrote.
+        // The transmittance (d0) exists only for the few walks of which a segment crossed a medium (sd.w == 2). For every
+        // other walk it is (1, 1, 1).
         bool light_loaded = false, light_changed = false;
         if (have) {
             c2 = c2_in;
             unpack_flags(P, __float_as_uint(c2.y));
-            if (P.sh_inside || __float_as_int(sd4.w) == 2) {
+            if (__float_as_int(sd4.w) == 2) {
                 float4 l0 = w.Sc.d0[i];
-                P.light = f3(l0.x, l0.y, l0.z); P.env_pdf = l0.w;
+                P.light = f3(l0.x, l0.y, l0.z);
                 light_loaded = true;
             }
             P.so = f3(0.f, 0.f, 0.f); P.sd = f3(sd4.x, sd4.y, sd4.z);
@@ -1051,7 +1062,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
         if (to_bsdf) {
             // the walk's result stays in the record: transmittance (where a medium changed it), state and the draws
             // it consumed
-            if (light_changed) w.Sc.d0[i] = make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf);
+            if (light_changed) {
+                w.Sc.d0[i] = make_float4(P.light.x, P.light.y, P.light.z, 0.f);
+                if (!light_loaded) w.Sc.sd[i] = make_float4(sd4.x, sd4.y, sd4.z, __int_as_float(2));
+            }
             w.Sc.c2[i] = make_float4(c2.x, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), c2.w);
             w.bsdf_list[stripe_pos(stripe, s_list_base + first + rank)] = i;
         }
@@ -1061,10 +1075,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
             const float4 so4 = w.Sc.so[i];
             const F3 o = f3(so4.x, so4.y, so4.z) + P.so;
             w.Sn.so[j] = make_float4(o.x, o.y, o.z, so4.w);
-            w.Sn.sd[j] = make_float4(sd4.x, sd4.y, sd4.z, __int_as_float(light_loaded ? 2 : 1));
+            const bool crossed = light_loaded || light_changed;
+            w.Sn.sd[j] = make_float4(sd4.x, sd4.y, sd4.z, __int_as_float(crossed ? 2 : 1));
             w.Sn.c0[j] = w.Sc.c0[i]; w.Sn.c1[j] = w.Sc.c1[i];
             w.Sn.c2[j] = make_float4(c2.x, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), c2.w);
-            w.Sn.d0[j] = light_loaded ? make_float4(P.light.x, P.light.y, P.light.z, P.env_pdf) : w.Sc.d0[i];
+            if (crossed) w.Sn.d0[j] = make_float4(P.light.x, P.light.y, P.light.z, 0.f);
             w.Sn.d1[j] = w.Sc.d1[i];
             w.Sn.e0[j] = w.Sc.e0[i]; w.Sn.e1[j] = w.Sc.e1[i]; w.Sn.e4[j] = w.Sc.e4[i];
         }
