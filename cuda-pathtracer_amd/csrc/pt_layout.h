@@ -128,8 +128,8 @@ struct DCounters {
 
 // ---------------------------------------------------------------- wavefront queues
 // A sample in flight is one record in one of two queues, by what it waits for: the closest hit of its path ray
-// (path queue, 48 bytes) or of a segment of the visibility walk of its light sample (shadow queue, 160 bytes: the
-// path state, the light sample and the vertex the walk started from). Both are structures of 16-byte arrays indexed
+// (path queue, 48 bytes) or of a segment of the visibility walk of its light sample (shadow queue, 128 bytes as a
+// vertex writes it, 160 with the arrays few records need: the path state, the light sample and the vertex the walk started from). Both are structures of 16-byte arrays indexed
 // by queue position, and both are dense: every stage reads the current queues front to back and appends what it
 // produces to the next ones (positions handed out by one atomic per workgroup and queue), so a wave's 64 records
 // are consecutive and of one kind whatever the paths did before.
