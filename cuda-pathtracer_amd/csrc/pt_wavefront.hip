@@ -140,11 +140,11 @@ PT_DEV bool material_constants(const DScene& S, int mat_index, Mat& m)
     m.coat_rough = m3.x; m.strans = m3.y; m.ior = m3.w; m.G = m4.x;
     return __float_as_int(m6.z) != 0;
 }
-PT_DEV uint32_t load_shadow(const WfShadowQueue& q, uint32_t i, const WfParams& w, const DScene& S, Path& P, SampleId& id)
+// (everything but the path state, which the caller has loaded: P.pdf holds the word that travels in its place)
+PT_DEV void load_vertex(const WfShadowQueue& q, uint32_t i, const DScene& S, Path& P)
 {
     float4 so = q.so[i], sd = q.sd[i], l1 = q.d1[i];
     float4 a = q.e0[i], e = q.e4[i];
-    uint32_t sample = load_core(q.c0, q.c1, q.c2, i, w, P, id);
     P.so = f3(so.x, so.y, so.z); P.sd = f3(sd.x, sd.y, sd.z);
     // the transmittance of the walk so far is (1, 1, 1) unless a segment crossed a medium (marked in sd.w)
     P.light = f3(1.f, 1.f, 1.f);
@@ -156,6 +156,11 @@ PT_DEV uint32_t load_shadow(const WfShadowQueue& q, uint32_t i, const WfParams& 
     if (material_constants(S, __float_as_int(so.w), m)) { const float4 b = q.e1[i]; m.emis = f3(b.x, b.y, b.z); }
     P.vn = f3(e.x, e.y, e.z); m.alpha = e.w;
     m.sigA = f3(0.f, 0.f, 0.f); m.sigS = f3(0.f, 0.f, 0.f);     // not used after the vertex
+}
+PT_DEV uint32_t load_shadow(const WfShadowQueue& q, uint32_t i, const WfParams& w, const DScene& S, Path& P, SampleId& id)
+{
+    uint32_t sample = load_core(q.c0, q.c1, q.c2, i, w, P, id);
+    load_vertex(q, i, S, P);
     return sample;
 }
 
@@ -955,6 +960,130 @@ __global__ __launch_bounds__(kBlock) void wf_miss_kernel(WfParams w, DScene S, D
 #ifndef PT_SHADOW_WAVES
 #define PT_SHADOW_WAVES 8       // 71 registers: no spill at 8 (6: -1 % on the bench)
 #endif
+// What one segment makes of a record of the shadow queue.
+struct Walk {
+    bool have, to_bsdf, goes_on;        // the record waits for a hit; its walk has ended; it goes on with another segment
+    bool light_loaded, light_changed;   // the transmittance was in the record (d0); this segment changed it
+    uint32_t kind;                      // of work the bsdf stage will do for it
+    uint32_t flags, draws;              // the sample's state word and draw count after the segment
+    F3 light, step;                     // transmittance after the segment; what a walk that goes on adds to its origin
+    float4 sd4, c2;                     // the record's segment and state words as read
+};
+template <bool COUNT>
+PT_DEV void walk_segment(const WfParams& w, const DScene& S, const DCamera& cam, uint32_t i, bool in_block, Tally& tl, Walk& k)
+{
+    // (the hit and the state word are fetched with the segment, not after it: nearly every record of a launch that
+    // has any still waits for its hit, and the chain of dependent loads is one shorter)
+    float4 sd4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = sd4, c2_in = sd4;
+    if (in_block) { sd4 = w.Sc.sd[i]; h4 = w.hitS[i]; c2_in = w.Sc.c2[i]; }
+    // (every record of the queue carries a pending ray, marked in sd.w; the check guards the material index behind it)
+    const bool have = in_block && __float_as_int(sd4.w) != 0;
+    Path P;
+    P.state = ST_DONE; P.lobes = 0; P.nee_surface = false; P.nee_skip = false;
+    P.light = f3(1.f, 1.f, 1.f); P.env_pdf = 0.f;
+    P.so = f3(0.f, 0.f, 0.f); P.rng.draws = 0u;
+    float4 c2 = sd4;
+    // The transmittance (d0) exists only for the few walks of which a segment crossed a medium (sd.w == 2). For every
+    // other walk it is (1, 1, 1).
+    bool light_loaded = false, light_changed = false;
+    if (have) {
+        c2 = c2_in;
+        unpack_flags(P, __float_as_uint(c2.y));
+        if (__float_as_int(sd4.w) == 2) {
+            float4 l0 = w.Sc.d0[i];
+            P.light = f3(l0.x, l0.y, l0.z);
+            light_loaded = true;
+        }
+        P.so = f3(0.f, 0.f, 0.f); P.sd = f3(sd4.x, sd4.y, sd4.z);
+        Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
+        const bool in_medium = P.sh_inside;
+        // A material marked opaque at upload ends the walk whatever the hit point: the alpha test draws its
+        // number and fails, the transmittance is zero (pathtracer.cu:279-295). Most hits are of this kind and
+        // skip the texture coordinates, the material record, the texels and the random-number block.
+        bool opaque = false;
+        if (!COUNT && h.tri != PT_NO_TRI) opaque = S.tri_info ? (S.tri_info[h.tri] >> 31) != 0 : S.mats[S.tri_ref[h.tri].matIndex].opaque != 0;
+        if (opaque) {
+            P.rng.draws = __float_as_uint(c2.z) + 1u;
+            P.light = f3(0.f, 0.f, 0.f);
+            P.state = ST_AFTER;
+        } else {
+            const SampleId id = decode_sample(w, __float_as_uint(c2.w));
+            rng_seed(P.rng, id.pixel, (uint32_t)id.frame, __float_as_uint(c2.z));
+            Surf info;
+            resolve_hit<COUNT>(S, h, P.sd, info, tl.taps, tl.taps_r, true);
+            on_shadow_hit<COUNT>(S, cam, P, info, tl);
+            light_changed = in_medium && info.hit;
+        }
+        if (P.state == ST_AFTER && dot(P.light, P.light) <= 0.05f) {
+            // Blocked (or all but): the test of pathtracer.cu:318 is taken here and the record says so through
+            // the flag that skips the light's term, so the transmittance is not passed on.
+            P.nee_skip = true;
+            light_changed = false;
+        }
+    }
+    k.have = have;
+    k.to_bsdf = have && P.state == ST_AFTER;
+    k.goes_on = have && P.state == ST_SHADOW;
+    // Order of a workgroup's entries for the bsdf stage: by which lobes the material carries (the branches of
+    // DisneyEval_2, disney.cuh:294-344), surface or medium vertex, and whether the light sample arrived (its
+    // evaluation is skipped otherwise, pathtracer.cu:318).
+    k.kind = 0;
+    if (k.to_bsdf) {
+        const bool lit = !P.nee_skip && !(dot(P.light, P.light) <= 0.05f);
+        k.kind = (uint32_t)(P.lobes & 15) | (P.nee_surface ? 0u : 16u) | (lit ? 32u : 0u);
+    }
+    k.light_loaded = light_loaded; k.light_changed = light_changed;
+    k.flags = have ? pack_flags(P) : 0u; k.draws = P.rng.draws;
+    k.light = P.light; k.step = P.so;
+    k.sd4 = sd4; k.c2 = c2;
+}
+// Counting sort of a workgroup's finished walks by kind, in LDS (s_kind[64], cleared before the walks' segments and a
+// barrier): the waves of the bsdf stage then run mostly one kind each instead of every branch for a few lanes. Every
+// thread calls it; returns the number of finished walks of the block and, for each, its place among them.
+PT_DEV uint32_t sort_by_kind(uint32_t* s_kind, bool to_bsdf, uint32_t kind, uint32_t& place)
+{
+    const int lane = (int)(threadIdx.x & 63u);
+    uint32_t rank = 0;
+    // one LDS atomic per kind a wave holds (a wave's lanes are mostly of one or two kinds: per-lane atomics on
+    // one word would be served one after the other)
+    for (unsigned long long todo = __ballot(to_bsdf); todo != 0ull;) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const uint32_t k = (uint32_t)__shfl((int)kind, leader, 64);
+        const bool mine = to_bsdf && kind == k;
+        const unsigned long long same = __ballot(mine);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&s_kind[k], (uint32_t)__popcll(same));
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (mine) rank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    __syncthreads();
+    // exclusive prefix over the kinds, computed by every wave for itself (lane l holds kind l)
+    const uint32_t held = s_kind[lane];
+    uint32_t incl = held;
+#pragma unroll
+    for (int dlt = 1; dlt < 64; dlt <<= 1) {
+        uint32_t t = (uint32_t)__shfl_up((int)incl, dlt, 64);
+        if (lane >= dlt) incl += t;
+    }
+    place = (uint32_t)__shfl((int)(incl - held), (int)kind, 64) + rank;
+    return (uint32_t)__shfl((int)incl, 63, 64);
+}
+// a walk that goes on: its record, with the next segment, moves to position j of the next shadow queue
+PT_DEV void store_next_segment(const WfParams& w, uint32_t i, uint32_t j, const Walk& k)
+{
+    // (k.step holds the step along the ray from the record's origin)
+    const float4 so4 = w.Sc.so[i];
+    const F3 o = f3(so4.x, so4.y, so4.z) + k.step;
+    w.Sn.so[j] = make_float4(o.x, o.y, o.z, so4.w);
+    const bool crossed = k.light_loaded || k.light_changed;
+    w.Sn.sd[j] = make_float4(k.sd4.x, k.sd4.y, k.sd4.z, __int_as_float(crossed ? 2 : 1));
+    w.Sn.c0[j] = w.Sc.c0[i]; w.Sn.c1[j] = w.Sc.c1[i];
+    w.Sn.c2[j] = make_float4(k.c2.x, __uint_as_float(k.flags), __uint_as_float(k.draws), k.c2.w);
+    if (crossed) w.Sn.d0[j] = make_float4(k.light.x, k.light.y, k.light.z, 0.f);
+    w.Sn.d1[j] = w.Sc.d1[i];
+    w.Sn.e0[j] = w.Sc.e0[i]; w.Sn.e1[j] = w.Sc.e1[i]; w.Sn.e4[j] = w.Sc.e4[i];
+}
 template <bool COUNT>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADOW_WAVES))) void wf_shadow_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
 {
@@ -963,7 +1092,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
     __shared__ uint32_t s_list_base;
     __shared__ uint32_t counts[kStripes];
     BlockCursor bc = first_block(w.counters + WF_CTR_SEG_SHADOW, w.counters + WF_CTR_N_S, 1, counts);
-    const int lane = (int)(threadIdx.x & 63u);
     Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
     for (;;) {
         if (threadIdx.x < kKinds) s_kind[threadIdx.x] = 0u;
@@ -971,118 +1099,25 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_SHADO
         if (blk == kNone) break;
         const uint32_t stripe = blk & (uint32_t)(kStripes - 1);
         const uint32_t i = blk * kBlock + threadIdx.x;
-        const bool in_block = threadIdx.x < block_fill(blk, counts);
-        // (the hit and the state word are fetched with the segment, not after it: nearly every record of a launch that
-        // has any still waits for its hit, and the chain of dependent loads is one shorter)
-        float4 sd4 = make_float4(0.f, 0.f, 0.f, 0.f), h4 = sd4, c2_in = sd4;
-        if (in_block) { sd4 = w.Sc.sd[i]; h4 = w.hitS[i]; c2_in = w.Sc.c2[i]; }
-        // (every record of the queue carries a pending ray, marked in sd.w; the check guards the material index behind it)
-        const bool have = in_block && __float_as_int(sd4.w) != 0;
-        Path P;
-        P.state = ST_DONE; P.lobes = 0; P.nee_surface = false; P.nee_skip = false;
-        P.light = f3(1.f, 1.f, 1.f); P.env_pdf = 0.f;
-        float4 c2 = sd4;
-        // The transmittance (d0) exists only for the few walks of which a segment crossed a medium (sd.w == 2). For every
-        // other walk it is (1, 1, 1).
-        bool light_loaded = false, light_changed = false;
-        if (have) {
-            c2 = c2_in;
-            unpack_flags(P, __float_as_uint(c2.y));
-            if (__float_as_int(sd4.w) == 2) {
-                float4 l0 = w.Sc.d0[i];
-                P.light = f3(l0.x, l0.y, l0.z);
-                light_loaded = true;
-            }
-            P.so = f3(0.f, 0.f, 0.f); P.sd = f3(sd4.x, sd4.y, sd4.z);
-            Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
-            const bool in_medium = P.sh_inside;
-            // A material marked opaque at upload ends the walk whatever the hit point: the alpha test draws its
-            // number and fails, the transmittance is zero (pathtracer.cu:279-295). Most hits are of this kind and
-            // skip the texture coordinates, the material record, the texels and the random-number block.
-            bool opaque = false;
-            if (!COUNT && h.tri != PT_NO_TRI) opaque = S.tri_info ? (S.tri_info[h.tri] >> 31) != 0 : S.mats[S.tri_ref[h.tri].matIndex].opaque != 0;
-            if (opaque) {
-                P.rng.draws = __float_as_uint(c2.z) + 1u;
-                P.light = f3(0.f, 0.f, 0.f);
-                P.state = ST_AFTER;
-            } else {
-                const SampleId id = decode_sample(w, __float_as_uint(c2.w));
-                rng_seed(P.rng, id.pixel, (uint32_t)id.frame, __float_as_uint(c2.z));
-                Surf info;
-                resolve_hit<COUNT>(S, h, P.sd, info, tl.taps, tl.taps_r, true);
-                on_shadow_hit<COUNT>(S, cam, P, info, tl);
-                light_changed = in_medium && info.hit;
-            }
-            if (P.state == ST_AFTER && dot(P.light, P.light) <= 0.05f) {
-                // Blocked (or all but): the test of pathtracer.cu:318 is taken here and the record says so through
-                // the flag that skips the light's term, so d0 is not rewritten.
-                P.nee_skip = true;
-                light_changed = false;
-            }
-        }
-        const bool to_bsdf = have && P.state == ST_AFTER;
-        const bool goes_on = have && P.state == ST_SHADOW;
-        // Order of this workgroup's entries of the bsdf list: by which lobes the material carries (the branches of
-        // DisneyEval_2, disney.cuh:294-344), surface or medium vertex, and whether the light sample arrived (its
-        // evaluation is skipped otherwise, pathtracer.cu:318). A counting sort in LDS: the waves of the bsdf stage then
-        // run mostly one kind each instead of every branch for a few lanes.
-        uint32_t kind = 0, rank = 0;
-        if (to_bsdf) {
-            const bool lit = !P.nee_skip && !(dot(P.light, P.light) <= 0.05f);
-            kind = (uint32_t)(P.lobes & 15) | (P.nee_surface ? 0u : 16u) | (lit ? 32u : 0u);
-        }
-        // one LDS atomic per kind a wave holds (a wave's lanes are mostly of one or two kinds: per-lane atomics on
-        // one word would be served one after the other)
-        for (unsigned long long todo = __ballot(to_bsdf); todo != 0ull;) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t k = (uint32_t)__shfl((int)kind, leader, 64);
-            const bool mine = to_bsdf && kind == k;
-            const unsigned long long same = __ballot(mine);
-            uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&s_kind[k], (uint32_t)__popcll(same));
-            base = (uint32_t)__shfl((int)base, leader, 64);
-            if (mine) rank = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
-            todo &= ~same;
-        }
-        __syncthreads();
-        // exclusive prefix over the kinds, computed by every wave for itself (lane l holds kind l)
-        const uint32_t held = s_kind[lane];
-        uint32_t incl = held;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            uint32_t t = (uint32_t)__shfl_up((int)incl, dlt, 64);
-            if (lane >= dlt) incl += t;
-        }
-        const uint32_t first = (uint32_t)__shfl((int)(incl - held), (int)kind, 64);
-        const uint32_t listed = (uint32_t)__shfl((int)incl, 63, 64);
+        Walk k;
+        walk_segment<COUNT>(w, S, cam, i, threadIdx.x < block_fill(blk, counts), tl, k);
+        uint32_t place = 0;
+        const uint32_t listed = sort_by_kind(s_kind, k.to_bsdf, k.kind, place);
         if (threadIdx.x == 0) s_list_base = listed ? atomicAdd(w.counters + WF_CTR_TAIL_B + stripe * (uint32_t)kStripeWords, listed) : 0u;
         Appends a;
-        a.want[0] = goes_on; a.tail[0] = w.counters + WF_CTR_TAIL_S;
+        a.want[0] = k.goes_on; a.tail[0] = w.counters + WF_CTR_TAIL_S;
         reserve<1>(a, stripe);                      // (its barriers also publish s_list_base and protect s_kind)
-        if (to_bsdf) {
+        if (k.to_bsdf) {
             // the walk's result stays in the record: transmittance (where a medium changed it), state and the draws
             // it consumed
-            if (light_changed) {
-                w.Sc.d0[i] = make_float4(P.light.x, P.light.y, P.light.z, 0.f);
-                if (!light_loaded) w.Sc.sd[i] = make_float4(sd4.x, sd4.y, sd4.z, __int_as_float(2));
+            if (k.light_changed) {
+                w.Sc.d0[i] = make_float4(k.light.x, k.light.y, k.light.z, 0.f);
+                if (!k.light_loaded) w.Sc.sd[i] = make_float4(k.sd4.x, k.sd4.y, k.sd4.z, __int_as_float(2));
             }
-            w.Sc.c2[i] = make_float4(c2.x, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), c2.w);
-            w.bsdf_list[stripe_pos(stripe, s_list_base + first + rank)] = i;
+            w.Sc.c2[i] = make_float4(k.c2.x, __uint_as_float(k.flags), __uint_as_float(k.draws), k.c2.w);
+            w.bsdf_list[stripe_pos(stripe, s_list_base + place)] = i;
         }
-        if (goes_on) {
-            const uint32_t j = a.pos[0];
-            // (P.so holds the step along the ray from the record's origin, see above)
-            const float4 so4 = w.Sc.so[i];
-            const F3 o = f3(so4.x, so4.y, so4.z) + P.so;
-            w.Sn.so[j] = make_float4(o.x, o.y, o.z, so4.w);
-            const bool crossed = light_loaded || light_changed;
-            w.Sn.sd[j] = make_float4(sd4.x, sd4.y, sd4.z, __int_as_float(crossed ? 2 : 1));
-            w.Sn.c0[j] = w.Sc.c0[i]; w.Sn.c1[j] = w.Sc.c1[i];
-            w.Sn.c2[j] = make_float4(c2.x, __uint_as_float(pack_flags(P)), __uint_as_float(P.rng.draws), c2.w);
-            if (crossed) w.Sn.d0[j] = make_float4(P.light.x, P.light.y, P.light.z, 0.f);
-            w.Sn.d1[j] = w.Sc.d1[i];
-            w.Sn.e0[j] = w.Sc.e0[i]; w.Sn.e1[j] = w.Sc.e1[i]; w.Sn.e4[j] = w.Sc.e4[i];
-        }
+        if (k.goes_on) store_next_segment(w, i, a.pos[0], k);
     }
     flush_tally<COUNT>(ctr, tl, 0);
 }
@@ -1121,6 +1156,78 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_BSDF_
         a.want[0] = have && P.state == ST_PATH; a.tail[0] = w.counters + WF_CTR_TAIL_P;
         reserve<1>(a, stripe);
         if (a.want[0]) store_path(w.Pn, a.pos[0], P, sample);
+    }
+    flush_tally<COUNT>(ctr, tl, nsamples);
+}
+
+// ---------------------------------------------------------------- shadow and bsdf stages in one kernel
+// The two stages above on one block of the shadow queue at a time: the block's segments, the sort of its finished walks
+// by kind, then the bsdf stage for them in sorted order (thread t takes the t-th finished walk). What a walk leaves for
+// the bsdf stage (state word, draw count, transmittance) goes through LDS instead of the record, and there is no list.
+// Same images. Measured on the bench against the two kernels: -0.5 % at three waves per SIMD (the segments' two dependent
+// loads are hidden by eight waves in a kernel of their own, not by three), +0.35 % at four (35 spilled registers): not
+// enabled (-DPT_FUSED_LIGHT=1 -DPT_BSDF_WAVES=4).
+#ifndef PT_FUSED_LIGHT
+#define PT_FUSED_LIGHT 0
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(PT_BSDF_WAVES))) void wf_light_kernel(WfParams w, DScene S, DCamera cam, DCounters* ctr)
+{
+    constexpr int kKinds = 64;
+    __shared__ uint32_t s_kind[kKinds];
+    __shared__ uint32_t counts[kStripes];
+    __shared__ uint32_t s_from[kBlock];         // which record of the block the t-th finished walk is
+    __shared__ uint2 s_state[kBlock];           // per record of the block: state word and draw count after the walk
+    __shared__ float4 s_light[kBlock];          // transmittance after the walk (w != 0: this segment changed it)
+    BlockCursor bc = first_block(w.counters + WF_CTR_SEG_SHADOW, w.counters + WF_CTR_N_S, 1, counts);
+    Tally tl = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t nsamples = 0;
+    for (;;) {
+        if (threadIdx.x < kKinds) s_kind[threadIdx.x] = 0u;
+        const uint32_t blk = next_block(w.counters + WF_CTR_SEG_SHADOW, counts, bc);      // (its barriers also publish the cleared counts)
+        if (blk == kNone) break;
+        const uint32_t stripe = blk & (uint32_t)(kStripes - 1);
+        const uint32_t i = blk * kBlock + threadIdx.x;
+        uint32_t listed;
+        {
+            Walk k;
+            walk_segment<COUNT>(w, S, cam, i, threadIdx.x < block_fill(blk, counts), tl, k);
+            uint32_t place = 0;
+            listed = sort_by_kind(s_kind, k.to_bsdf, k.kind, place);
+            if (k.to_bsdf) {
+                s_from[place] = threadIdx.x;
+                s_state[threadIdx.x] = make_uint2(k.flags, k.draws);
+                s_light[threadIdx.x] = make_float4(k.light.x, k.light.y, k.light.z, k.light_changed ? 1.f : 0.f);
+            }
+            Appends a;
+            a.want[0] = k.goes_on; a.tail[0] = w.counters + WF_CTR_TAIL_S;
+            reserve<1>(a, stripe);                  // (its barriers also publish the three arrays and protect s_kind)
+            if (k.goes_on) store_next_segment(w, i, a.pos[0], k);
+        }
+        const bool have = threadIdx.x < listed;
+        Path P;
+        SampleId id = {0, 0, 0, 0u, 0u};
+        uint32_t sample = kNone;
+        P.state = ST_DONE;
+        bool finished = false;
+        if (have) {
+            const uint32_t from = s_from[threadIdx.x];
+            const uint32_t r = blk * kBlock + from;
+            float4 c0 = w.Sc.c0[r], c1 = w.Sc.c1[r], c2 = w.Sc.c2[r];
+            const uint2 st = s_state[from];
+            c2.y = __uint_as_float(st.x); c2.z = __uint_as_float(st.y);
+            sample = unpack_core(c0, c1, c2, w, P, id);
+            load_vertex(w.Sc, r, S, P);
+            const float4 l = s_light[from];
+            if (l.w != 0.f) P.light = f3(l.x, l.y, l.z);
+            after_light<COUNT>(S, cam, P, tl);
+            finished = P.state == ST_DONE;
+        }
+        finish_and_regenerate<COUNT>(w, cam, P, sample, id, finished, nsamples);
+        Appends ap;
+        ap.want[0] = have && P.state == ST_PATH; ap.tail[0] = w.counters + WF_CTR_TAIL_P;
+        reserve<1>(ap, stripe);
+        if (ap.want[0]) store_path(w.Pn, ap.pos[0], P, sample);
     }
     flush_tally<COUNT>(ctr, tl, nsamples);
 }
@@ -1365,8 +1472,13 @@ void launch_wf_iteration(const WfParams& w, const DScene& S, const DCamera& cam,
     }
     if (ev) (void)hipEventRecord(ev[3], s);
     PT_STAGE(wf_miss_kernel, 4, w, S, cam, ctr);
-    PT_STAGE(wf_shadow_kernel, 5, w, S, cam, ctr);
-    PT_STAGE(wf_bsdf_kernel, 6, w, S, cam, ctr);
+    if (PT_FUSED_LIGHT) {
+        PT_STAGE(wf_light_kernel, 5, w, S, cam, ctr);
+        if (ev) (void)hipEventRecord(ev[6], s);
+    } else {
+        PT_STAGE(wf_shadow_kernel, 5, w, S, cam, ctr);
+        PT_STAGE(wf_bsdf_kernel, 6, w, S, cam, ctr);
+    }
 #undef PT_STAGE
 }
 
