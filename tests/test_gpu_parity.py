@@ -196,6 +196,25 @@ def test_sun_sky_mode_glossy_dielectric(mode):
     assert ctr['rays'] == st['rays']
 
 
+@pytest.mark.parametrize('mode', MODES)
+def test_emission_maps_on_every_surface(mode):
+    """image_loader.h:47-89 / pathtracer.cu:166-170: an emission map replaces the material's emission by its texel, on all
+    three channels. The Cornell box with a small emission map on every material (so every vertex of every path carries a
+    mapped emission through the queues) against the oracle, bit for bit."""
+    b = util.cornell('black')
+    mats = b.mats.copy()
+    glow = ((np.arange(64, dtype=np.float32).reshape(8, 8) * 37) % 61 / 255.0).astype(np.float32)[:, :, None]
+    handle = len(b.textures) + 1
+    mats['emissiveTexture'] = handle
+    mats['use_mapKe'] = 1
+    lit = util.Bundle(b.tris, mats, list(b.textures) + [glow], b.env, b.sky_mode)
+    P = scenes.cornell_params(ptamd.default_params(56, 40))
+    acc, ctr, img, want, st = _render_both(lit, P, 0, 4, 6, mode)
+    _assert_radiance(acc, want)
+    assert ctr['tex_taps_r'] == st['tex_taps_r'] and st['tex_taps_r'] >= st['shade_vertices'] > 0
+    assert want.sum() > 0
+
+
 @pytest.mark.parametrize('sky_mode', [pytest.param(0, id='environment_map'), pytest.param(1, id='sun_sky')])
 def test_material_table_larger_than_the_kernels_local_copy(sky_mode):
     """The path-hit kernel keeps up to 64 materials and 64 textures in LDS; a scene with more takes the variant that
