@@ -197,6 +197,37 @@ def test_sun_sky_mode_glossy_dielectric(mode):
 
 
 @pytest.mark.parametrize('mode', MODES)
+def test_index_matched_scattering_medium_in_the_cornell_box(mode):
+    """pathtracer.cu:279-295, :432-451: the two boxes of the Cornell box made of an index-matched scattering medium (ior
+    1.005, absorption and scattering on the scale of the room). Path rays scatter inside them (phase-function vertices with
+    light samples that start inside the medium), visibility walks cross them in several segments and carry a transmittance
+    other than (1, 1, 1) from segment to segment and on to the bsdf stage."""
+    b = util.cornell('black')
+    lo = np.minimum(np.minimum(b.tris['a'], b.tris['b']), b.tris['c']).min(0)
+    hi = np.maximum(np.maximum(b.tris['a'], b.tris['b']), b.tris['c']).max(0)
+    ext = float((hi - lo).max())
+    centre = (b.tris['a'] + b.tris['b'] + b.tris['c']) / 3
+    inside = ((centre > lo + 0.02 * ext) & (centre < hi - 0.02 * ext)).all(1) & (b.tris['matIndex'] == 0)
+    assert 10 <= inside.sum() <= 24
+    mats = np.concatenate([b.mats, b.mats[:1]])
+    fog = len(mats) - 1
+    mats['specTrans'][fog] = 1.0; mats['ior'][fog] = 1.005; mats['roughness'][fog] = 0.0; mats['G'][fog] = 0.6
+    mats['sigmaA'][fog] = np.float32(0.3 / ext) * np.array([1, 2, 4], np.float32)
+    mats['sigmaS'][fog] = np.float32(2.0 / ext)
+    tris = b.tris.copy()
+    tris['matIndex'][inside] = fog
+    foggy = util.Bundle(tris, mats, b.textures, b.env, b.sky_mode)
+    P = scenes.cornell_params(ptamd.default_params(56, 40))
+    acc, ctr, img, want, st = _render_both(foggy, P, 0, 4, 12, mode)
+    _assert_radiance(acc, want)
+    for k in ('rays', 'samples', 'shade_vertices', 'env_samples'):
+        assert ctr[k] == st[k], k
+    plain, _ = orc.render(b.oracle(P), P, 0, 4, 12)
+    assert st['rays'] > st['env_samples'] + st['shade_vertices']        # visibility walks of more than one segment
+    assert want.sum() > 0 and not np.array_equal(want, plain)
+
+
+@pytest.mark.parametrize('mode', MODES)
 def test_emission_maps_on_every_surface(mode):
     """image_loader.h:47-89 / pathtracer.cu:166-170: an emission map replaces the material's emission by its texel, on all
     three channels. The Cornell box with a small emission map on every material (so every vertex of every path carries a
