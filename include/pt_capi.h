@@ -172,7 +172,7 @@ int pt_render_frame(pt_ctx* ctx, pt_params* params);                    /* rende
 /* ---- textures and sky: image_loader.h:5-89, envmap.cpp:37-94 ---- */
 int pt_render_frame_async(pt_ctx* ctx, pt_params* params);              /* pt_render_frame without the wait (no counterpart in the reference, whose render() blocks in cudaMemcpy, pathtracer.cu:613-615): the image goes to one of two pinned host buffers on a copy stream while the caller goes on; at most two frames in flight; params->pixelBuffer is not written */
 int pt_frame_fetch(pt_ctx* ctx, uint8_t* rgba_out, const uint8_t** pinned_out, int* frame_index_out); /* the oldest frame in flight: waits for its copy; copies it to rgba_out and/or returns the pinned buffer (valid until the second pt_render_frame_async from now) */
-int pt_set_frame_lookahead(pt_ctx* ctx, int max_frames);               /* pt_render_frame: while the caller keeps asking for the next frame of one view, up to max_frames (default 8; 1 = never) are rendered per batch and each joins the accumulator when its call comes: same image per call, fewer ramp-ups */
+int pt_set_frame_lookahead(pt_ctx* ctx, int max_frames);               /* pt_render_frame: while the caller keeps asking for the next frame of one view, up to max_frames (default 32, at most 64; 1 = never) are rendered per batch and each joins the accumulator when its call comes: same image per call, fewer ramp-ups */
 int pt_upload_texture(pt_ctx* ctx, const float* texels, int w, int h, int comps, uint64_t* handle_out); /* comps 4 = genTexture, 1 = genTexture_float; rows already V-flipped */
 int pt_set_texture_packing(pt_ctx* ctx, int on);                        /* on (default): textures whose values are all exactly k/255 are stored as bytes; the sampled values are the same */
 int pt_upload_envmap(pt_ctx* ctx, const float* rgba, const float* cdf, int w, int h, float sum, pt_params* params_io); /* generateCUDAenvmap + transfertToParams */

@@ -11,6 +11,8 @@ P = scenes.atrium_params(ptamd.default_params(W, H))
 r = b.renderer(P)
 if os.environ.get('DRAIN'):
     r.set_drain(int(os.environ['DRAIN']))
+if os.environ.get('LOOKAHEAD'):
+    r.set_frame_lookahead(int(os.environ['LOOKAHEAD']))     # frames per batch at most (default 32)
 r.enable_counters(True); r.render(P, 0, n); rays = r.counters()['rays']; r.enable_counters(False)
 for f in range(4):
     P.frameIndex = f; r.render_frame(P)
