@@ -457,7 +457,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
             const pt_triangle& T = c->tris[id];
             seen[id] = 1;
             DTri r;
-            r.q0 = make_float4(T.a.x, T.a.y, T.a.z, __builtin_bit_cast(float, (uint32_t)id));
+            r.q0 = make_float4(T.a.x, T.a.y, T.a.z, __builtin_bit_cast(float, (uint32_t)id << 1));
             r.q1 = make_float4(T.b.x - T.a.x, T.b.y - T.a.y, T.b.z - T.a.z, __builtin_bit_cast(float, i == 0 ? nd.triCount : 0));
             r.q2 = make_float4(T.c.x - T.a.x, T.c.y - T.a.y, T.c.z - T.a.z, 0.f);
             dt.push_back(r);
@@ -586,7 +586,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
             TightBox b; for (int a = 0; a < 3; a++) { b.lo[a] = INFINITY; b.hi[a] = -INFINITY; }
             const int first = ~ref, count = leaf_count(ref);
             for (int j = first; j < first + count; j++) {
-                const pt_triangle& T = c->tris[__builtin_bit_cast(uint32_t, dt[(size_t)j].q0.w)];
+                const pt_triangle& T = c->tris[__builtin_bit_cast(uint32_t, dt[(size_t)j].q0.w) >> 1];
                 const float* v[3] = {&T.a.x, &T.b.x, &T.c.x};
                 for (int k = 0; k < 3; k++) for (int a = 0; a < 3; a++) { b.lo[a] = std::fmin(b.lo[a], v[k][a]); b.hi[a] = std::fmax(b.hi[a], v[k][a]); }
             }
@@ -753,6 +753,7 @@ int pt_upload_bvh(pt_ctx* c, const pt_bvh_node* nodes, int root_idx, int nodes_u
     c->n_nodes = dn.size();
     c->n_nodes4 = n4.size();
     c->have_bvh = true;
+    c->tri_flags_stale = true; c->scene.tri_info = nullptr;       // (the new records carry no opaque marks yet)
     lap("device copies");
     return PT_OK;
 }
@@ -799,6 +800,7 @@ int pt_build_bvh(pt_ctx* c, int flavour)
         c->scene.wide = (c->wide_fits && c->node_width == 4) ? 1 : 0;
         c->n_nodes = g.n_nodes; c->n_nodes4 = g.n_nodes4;
         c->have_bvh = true;
+        c->tri_flags_stale = true; c->scene.tri_info = nullptr;   // (the new records carry no opaque marks yet)
         return PT_OK;
     }
     std::vector<pt_bvh_node> nodes((size_t)2 * n - 1 + 1);
@@ -1063,6 +1065,10 @@ static int check_ready(pt_ctx* c, bool need_image)
         HIP_TRY(hipMalloc((void**)&c->d_tri_info, info.size() * sizeof(uint32_t)));
         HIP_TRY(hipMemcpy(c->d_tri_info, info.data(), info.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         c->scene.tri_info = c->d_tri_info;
+        // the same flag into the leaf-order records the traversal kernel tests (DTri::q0.w)
+        launch_mark_opaque_triangles(c->d_tris, (int)c->tris.size(), c->d_tri_info, c->stream);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));
         c->tri_flags_stale = false;
     }
     return PT_OK;

@@ -308,7 +308,7 @@ PT_DEV Hit closest_hit(const DScene& S, F3 o, F3 d, int tid, uint32_t& nbox, uin
             for (int i = 0; i < count; i++) {
                 float4 q0 = tp[i].q0, q1 = tp[i].q1, q2 = tp[i].q2;
                 if (i == 0) count = __float_as_int(q1.w);
-                uint32_t id = __float_as_uint(q0.w);
+                uint32_t id = __float_as_uint(q0.w) >> 1;       // (the id word carries a mark below the index, see DTri)
                 float t, u, v;
                 if (COUNT) ntri += 1;
                 if (!tri_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), o, d, best.t, t, u, v)) continue;
@@ -441,7 +441,7 @@ PT_DEV Hit closest_hit_wide(const DScene& S, F3 o, F3 d, int tid, uint32_t& nnod
             const int count = (int)(enc >> 26) + 1;
             for (int i = 0; i < count; i++) {
                 float4 q0 = tp[i].q0, q1 = tp[i].q1, q2 = tp[i].q2;
-                uint32_t id = __float_as_uint(q0.w);
+                uint32_t id = __float_as_uint(q0.w) >> 1;       // (the id word carries a mark below the index, see DTri)
                 float t, u, v;
                 if (COUNT) ntri += 1;
                 if (!tri_test(f3(q0.x, q0.y, q0.z), f3(q1.x, q1.y, q1.z), f3(q2.x, q2.y, q2.z), o, d, best.t, t, u, v)) continue;

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void gb_emit_tris(const pt_triangle* __restric
         const uint32_t id = ids[i];
         const pt_triangle& T = tris[id];
         DTri r;
-        r.q0 = make_float4(T.a.x, T.a.y, T.a.z, __uint_as_float(id));
+        r.q0 = make_float4(T.a.x, T.a.y, T.a.z, __uint_as_float(id << 1));
         r.q1 = make_float4(T.b.x - T.a.x, T.b.y - T.a.y, T.b.z - T.a.z, __int_as_float(1));
         r.q2 = make_float4(T.c.x - T.a.x, T.c.y - T.a.y, T.c.z - T.a.z, 0.f);
         out[i] = r;

@@ -117,6 +117,21 @@ void launch_render_samples(const DScene& S, const DCamera& cam, int frame_begin,
         hipLaunchKernelGGL(render_samples_kernel<false>, grid, block, 0, stream, S, cam, frame_begin, frame_end, accum_dev, ctr_dev);
 }
 
+// ---------------------------------------------------------------- opaque marks
+// Sets the mark in the id word of every leaf-order triangle record (DTri::q0.w) from its triangle's entry of DScene::tri_info.
+__global__ __launch_bounds__(256) void mark_opaque_triangles_kernel(DTri* __restrict__ tris, int n, const uint32_t* __restrict__ tri_info)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t id = __float_as_uint(tris[i].q0.w) >> 1;
+    tris[i].q0.w = __uint_as_float((id << 1) | (tri_info[id] >> 31));
+}
+
+void launch_mark_opaque_triangles(DTri* tris_dev, int n, const uint32_t* tri_info_dev, hipStream_t stream)
+{
+    hipLaunchKernelGGL(mark_opaque_triangles_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, tris_dev, n, tri_info_dev);
+}
+
 // ---------------------------------------------------------------- display resolve
 // pathtracer.cu:588-599: accum / frames -> AgX -> RGBA8
 __global__ __launch_bounds__(256) void resolve_display_kernel(const float* __restrict__ accum, int n_pixels, float frames, uint8_t* __restrict__ rgba)

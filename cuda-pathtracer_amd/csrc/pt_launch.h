@@ -6,6 +6,7 @@
 namespace ptamd {
 void launch_trace_closest(const DScene& S, const pt_ray* rays_dev, int n, pt_hit* hits_dev, uint32_t* nbox_dev, uint32_t* ntri_dev, hipStream_t stream);
 void launch_render_samples(const DScene& S, const DCamera& cam, int frame_begin, int frame_end, float* accum_dev, DCounters* ctr_dev, hipStream_t stream);
+void launch_mark_opaque_triangles(DTri* tris_dev, int n, const uint32_t* tri_info_dev, hipStream_t stream);
 void launch_resolve_display(const float* accum_dev, int n_pixels, int n_frames, uint8_t* rgba_dev, hipStream_t stream);
 void launch_post_process(const uint8_t* in_dev, int n_pixels, float exposure, const float* mult3, float saturation, float gamma, uint8_t* out_dev, hipStream_t stream);
 void launch_wf_generate(const WfParams& w, const DCamera& cam, DCounters* ctr, hipStream_t s);

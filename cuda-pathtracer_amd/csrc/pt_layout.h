@@ -47,7 +47,11 @@ struct __attribute__((aligned(64))) DNode4 {
 static_assert(sizeof(DNode4) == 64, "wide node must be 64 bytes");
 
 // Triangle record for intersection, 48 bytes = three 16-byte loads, stored in leaf order.
-// q0 = (a.xyz, original index), q1 = (b-a, triangles in this leaf [first record only]), q2 = (c-a, 0)
+// q0 = (a.xyz, id word), q1 = (b-a, triangles in this leaf [first record only]), q2 = (c-a, 0). The id word is twice
+// the triangle's original index, plus 1 when its material ends every visibility walk that hits it (DMat::opaque; set
+// once triangles, tree and materials are all there). Ordered like the indices, so ties between equal distances fall
+// as they do by index; the production traversal kernel reports the word as it is, and the shadow stage reads the mark
+// off it instead of looking anything up behind the hit.
 struct __attribute__((aligned(16))) DTri { float4 q0, q1, q2; };
 static_assert(sizeof(DTri) == 48, "triangle record must be 48 bytes");
 

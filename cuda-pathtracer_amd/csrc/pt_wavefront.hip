@@ -97,6 +97,9 @@ PT_DEV SampleId decode_sample(const WfParams& w, uint32_t s)
     return id;
 }
 
+// The triangle of a hit as the traversal kernel reports it: the id word of the record it tested (DTri::q0.w)
+PT_DEV uint32_t hit_triangle(uint32_t word) { return word == PT_NO_TRI ? PT_NO_TRI : word >> 1; }
+
 // ---- records in HBM: structures of 16-byte arrays indexed by queue position, so a wave's access is contiguous
 PT_DEV void store_core(float4* c0, float4* c1, float4* c2, uint32_t i, const Path& P, uint32_t sample)
 {
@@ -730,7 +733,7 @@ __global__ __launch_bounds__(kBlock) void wf_extend_kernel(WfParams w, DScene S,
         if (leaf_now) {
             const int count = WIDE ? leaf_count : __float_as_int(q1.w);
             auto test = [&](const float4& a0, const float4& a1, const float4& a2) {
-                uint32_t id = __float_as_uint(a0.w);
+                uint32_t id = __float_as_uint(a0.w);         // (twice the triangle's index, plus its opaque mark: see DTri. Hits carry it as it is)
                 float t, u, v;
                 if (COUNT) tl.tri += 1;
                 if (tri_test(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z), f3(a2.x, a2.y, a2.z), o, d, best.t, t, u, v) &&
@@ -865,7 +868,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(DIRECT ?
         const uint32_t i = blk * kBlock + threadIdx.x;
         const bool have = threadIdx.x < block_fill(blk, counts);
         Hit h; h.t = 0.f; h.tri = PT_NO_TRI; h.u = 0.f; h.v = 0.f;
-        if (have) { float4 h4 = w.hitP[i]; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w; }
+        if (have) { float4 h4 = w.hitP[i]; h.t = h4.x; h.tri = hit_triangle(__float_as_uint(h4.y)); h.u = h4.z; h.v = h4.w; }
         const bool hit = have && h.tri != PT_NO_TRI;
         Path P;
         SampleId id = {0, 0, 0, 0u, 0u};
@@ -995,13 +998,14 @@ PT_DEV void walk_segment(const WfParams& w, const DScene& S, const DCamera& cam,
             light_loaded = true;
         }
         P.so = f3(0.f, 0.f, 0.f); P.sd = f3(sd4.x, sd4.y, sd4.z);
-        Hit h; h.t = h4.x; h.tri = __float_as_uint(h4.y); h.u = h4.z; h.v = h4.w;
+        Hit h; h.t = h4.x; h.tri = hit_triangle(__float_as_uint(h4.y)); h.u = h4.z; h.v = h4.w;
         const bool in_medium = P.sh_inside;
         // A material marked opaque at upload ends the walk whatever the hit point: the alpha test draws its
         // number and fails, the transmittance is zero (pathtracer.cu:279-295). Most hits are of this kind and
-        // skip the texture coordinates, the material record, the texels and the random-number block.
+        // skip the texture coordinates, the material record, the texels and the random-number block. The mark comes with
+        // the hit (from the triangle record the traversal kernel tested), so nothing is looked up behind it.
         bool opaque = false;
-        if (!COUNT && h.tri != PT_NO_TRI) opaque = S.tri_info ? (S.tri_info[h.tri] >> 31) != 0 : S.mats[S.tri_ref[h.tri].matIndex].opaque != 0;
+        if (!COUNT && h.tri != PT_NO_TRI) opaque = S.tri_info ? (__float_as_uint(h4.y) & 1u) != 0 : S.mats[S.tri_ref[h.tri].matIndex].opaque != 0;
         if (opaque) {
             P.rng.draws = __float_as_uint(c2.z) + 1u;
             P.light = f3(0.f, 0.f, 0.f);
@@ -1366,7 +1370,7 @@ __global__ __launch_bounds__(kBlock) void wf_unpack_hits_kernel(const float4* __
     int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 h = hit[i];
-    pt_hit o; o.t = h.x; o.tri = __float_as_uint(h.y);
+    pt_hit o; o.t = h.x; o.tri = hit_triangle(__float_as_uint(h.y));
     out[i] = o;
 }
 // w: Sc.so, Sc.sd and hitS with room for n rounded up to whole blocks, counters, and the extend tuning
